@@ -1,0 +1,194 @@
+/*
+ * v2a_cfm.h -- C ABI of the MI355X (gfx950) kernels behind the flow-matching V2A sampler.
+ *
+ * The reference (acappemin/Video-to-Audio-and-Piano-RP) has no FFI/operator layer: the hot
+ * path is a Python class API (E2TTS.sample / transformer_with_pred_head) whose arithmetic
+ * runs as stock PyTorch ops.  Each entry point below therefore names the reference
+ * *module/function* it replaces (file:line, `x3` = src/e2_tts_pytorch/e2_tts_crossatt3.py;
+ * `xt` = third-party x-transformers==1.37.4, requirements.txt:19, call sites given).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says `host`;
+ *   - no allocation, no synchronisation, no global state inside: the caller owns every
+ *     buffer and passes the stream; all launches are graph-capturable;
+ *   - return value 0 = ok, negative = error; v2a_last_error() gives the message of the
+ *     last failing call on the calling thread;
+ *   - "compute dtype" T is V2A_F32 (parity mode, exact-fp32 MFMA) or V2A_BF16 (bf16
+ *     operands, fp32 accumulate).  Residual streams are always fp32;
+ *   - a "step vector" is a float vector selected per launch by a device-side step counter
+ *     and per row by its batch:  v = base + step[0]*step_stride + batch*batch_stride,
+ *     batch = row / rows_per_batch.  step may be NULL (= 0).  This is how the per-Euler-step
+ *     AdaLN / AdaptiveRMSNorm modulation tables are addressed from ONE captured hipGraph.
+ */
+#ifndef V2A_CFM_H
+#define V2A_CFM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* v2a_stream_t; /* hipStream_t */
+
+enum { V2A_F32 = 0, V2A_BF16 = 1 };
+
+enum {
+  V2A_OK = 0,
+  V2A_ERR_ARG = -1,    /* shape/alignment/enum the kernels do not support */
+  V2A_ERR_LAUNCH = -2  /* hipGetLastError() after launch */
+};
+
+int v2a_abi_version(void);
+const char* v2a_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * GEMM with fused epilogues:  acc[m][n] = sum_k A[m][k] * W[n][k]      (nn.Linear layout)
+ * A is the virtual concatenation along K of up to 3 row-major segments (so
+ * TextAudioCrossCondition's pack((audio,text,frames)) x3:693-700 and the U-Net skip
+ * torch.cat((x, skip)) x3:1116-1117 are never materialised).
+ * Replaces: every nn.Linear on the path -- xt Attention.to_q/to_k/to_v/to_out (sites
+ * x3:808,813,881,914), xt FeedForward (x3:817,884,917), TextAudioCrossCondition
+ * x3:698-700, skip_proj x3:1117, to_pred x3:2083, AdaLNZero.to_gamma x3:550 and
+ * AdaptiveRMSNorm.to_gamma (table build).
+ * ------------------------------------------------------------------------------------- */
+enum {
+  V2A_EPI_STORE = 0,      /* out = acc + bias                                    */
+  V2A_EPI_SIGMOID = 1,    /* out = sigmoid(acc + bias)            (AdaLNZero table) */
+  V2A_EPI_GEGLU = 2,      /* W rows packed [16 value | 16 gate] per 16 outputs:
+                             out[m][j] = (acc_v + b_v) * gelu_erf(acc_g + b_g); out has N/2 cols */
+  V2A_EPI_RESID = 3,      /* out = resid + acc + bias             (text/frames streams, cross-condition) */
+  V2A_EPI_GATE_RESID = 4  /* out = resid + gate[n] * (acc + bias) (AdaLNZero x3:546-551 + residual x3:1128) */
+};
+
+typedef struct v2a_gemm_args {
+  const void* a[3];      /* segment base pointers                                       */
+  int64_t lda[3];        /* row stride of each segment, in elements                     */
+  int32_t ka[3];         /* K extent of each segment; each a multiple of 64 (bf16) / 16 (f32) */
+  int32_t nseg;          /* 1..3                                                        */
+  int32_t a_dtype;       /* V2A_F32 or V2A_BF16; f32 A with bf16 compute is converted on load */
+  const void* w;         /* [N][K] row-major, compute dtype, K = sum ka                 */
+  int64_t ldw;
+  const float* bias;     /* [N] or NULL                                                 */
+  int32_t M, N;
+  int32_t compute_dtype; /* V2A_F32 | V2A_BF16                                          */
+  int32_t epilogue;      /* V2A_EPI_*                                                   */
+  void* out;             /* [M][N] (GEGLU: [M][N/2])                                    */
+  int64_t ldo;
+  int32_t out_dtype;     /* V2A_F32 | V2A_BF16 (RESID/GATE_RESID/SIGMOID: f32 only)     */
+  const float* resid;    /* [M][ldr] f32; may alias out                                 */
+  int64_t ldr;
+  const float* gate;     /* step vector of length N (GATE_RESID)                        */
+  const int32_t* step;
+  int64_t gate_step_stride, gate_batch_stride;
+  int32_t rows_per_batch;
+} v2a_gemm_args;
+
+int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RMSNorm / AdaptiveRMSNorm:  y = x / max(|x|_2, 1e-12) * sqrt(d) * gamma
+ * gamma is a step vector: RMSNorm passes g (strides 0); AdaptiveRMSNorm passes the
+ * precomputed (to_gamma(c) + 1) table.  Output in the compute dtype (GEMM operand).
+ * Replaces: xt RMSNorm (x3:880,883,913,916,935), xt AdaptiveRMSNorm (x3:807,812,816).
+ * ------------------------------------------------------------------------------------- */
+int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t y_dtype,
+                int64_t rows, int32_t d,
+                const float* gamma, const int32_t* step, int64_t gamma_step_stride,
+                int64_t gamma_batch_stride, int32_t rows_per_batch, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Position-generating depthwise conv, fused with mask, SiLU and the caller's residual:
+ *   out[b,n,:] = x[b,n,:] + m[b,n] * silu(bias + sum_j wt[j,:] * (m*x)[b, n+j-k/2, :])
+ * m[b,n] = n < len[b] (len NULL = all valid).  wt is the Conv1d weight transposed to
+ * [k][d].  out may alias x only if out == x is NOT used (the kernel reads a halo): pass a
+ * different buffer.
+ * Replaces: DepthwiseConv x3:495-528 + the `+ x` at x3:1082,1097,1122.
+ * ------------------------------------------------------------------------------------- */
+int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias,
+                             int32_t B, int32_t N, int32_t d, int32_t ksize,
+                             const int32_t* len, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Rotary embedding applied in place to `nheads` consecutive 64-wide heads of every row
+ * (the q and k column blocks of the fused QKV GEMM output).
+ * position of row r = pos_offset + (r % rows_per_batch); table cs[pos][32][2] = (cos,sin)
+ * of pos * 10000^(-2i/64).  layout 0 = interleaved pairs (2i,2i+1), 1 = half split (i,i+32).
+ * Replaces: xt RotaryEmbedding.forward_from_seq_len + apply_rotary_pos_emb
+ * (x3:779-781,983,988,994 and the rotary_pos_emb argument at x3:1084,1099,1126,1131).
+ * ------------------------------------------------------------------------------------- */
+int v2a_rope_inplace(void* qk, int32_t dtype, int64_t rows, int64_t row_stride, int32_t nheads,
+                     int32_t rows_per_batch, int32_t pos_offset, const float* cs_table,
+                     int32_t layout, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Soft-clamped, key-masked, head-gated attention core (dim_head = 64):
+ *   s = clamp * tanh(scale * q.k / clamp);  p = softmax_j(s | j < kv_len[b]);
+ *   o[b,i,h,:] = sigmoid(gate[b,i,h]) * sum_j p_j v[b,j,h,:];  rows i >= q_len[b] -> 0
+ * q/k/v/gate/out are addressed as base + b*batch_stride + token*row_stride + h*64 (+c)
+ * (gate: + h), so they can live inside the fused [q|k|v|gate] GEMM output.
+ * Replaces: xt Attention forward minus its Linears (attend + to_v_head_gate epilogue +
+ * out.masked_fill), sites x3:808,813,881,914,1084,1099,1126,1131.
+ * ------------------------------------------------------------------------------------- */
+typedef struct v2a_attn_args {
+  const void *q, *k, *v, *gate;
+  void* out;
+  int64_t q_row_stride, k_row_stride, v_row_stride, gate_row_stride, out_row_stride;
+  int64_t q_batch_stride, k_batch_stride, v_batch_stride, gate_batch_stride, out_batch_stride;
+  int32_t B, H, Nq, Nk;
+  const int32_t* kv_len; /* [B] or NULL (= Nk) */
+  const int32_t* q_len;  /* [B] or NULL (= Nq) */
+  float scale, softclamp;
+  int32_t dtype;         /* compute dtype of q,k,v,gate,out */
+} v2a_attn_args;
+
+int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Small fp32 linear with output row scatter (K arbitrary, VALU):
+ *   out[(m / T)*out_batch_stride + (row_off + m % T)*d + n] =
+ *        bias[n] + add[(m % T)*d + n] + sum_k a[m*K + k] * wt[k*d + n]
+ * and, when `dup_batch_offset` > 0, the same value again at batch (m/T + dup_batch_offset)
+ * (cond and null CFG halves share proj_in(x) + abs_pos_emb).
+ * Replaces: proj_in x3:2027 + abs_pos_emb x3:957-960 + register pack x3:975-976;
+ * proj_frames x3:2069.
+ * ------------------------------------------------------------------------------------- */
+int v2a_linear_small(const float* a, int64_t M, int32_t K, const float* wt, const float* bias,
+                     const float* add, int32_t T, float* out, int64_t out_batch_stride,
+                     int32_t row_off, int32_t d, int32_t dup_batch_offset, v2a_stream_t stream);
+
+/* out[b, r, :] = regs[r, :] for r < R, b < B  (register tokens, x3:975-997) */
+int v2a_fill_registers(float* out, int64_t out_batch_stride, const float* regs, int32_t B,
+                       int32_t R, int32_t d, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Time conditioning for every grid point at once:
+ *   out[s,:] = silu(bias + Wt^T [t_s, sin(2 pi t_s w), cos(2 pi t_s w)])
+ * wt = Linear(d+1, d).weight transposed to [d+1][d].
+ * Replaces: RandomFourierEmbed x3:555-564 + time_cond_mlp x3:793-797,966-971.
+ * ------------------------------------------------------------------------------------- */
+int v2a_time_cond(const float* t, int32_t S, const float* fourier_w, const float* wt,
+                  const float* bias, float* out, int32_t d, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * CFG combine + explicit Euler update, in place on y (B, T, C):
+ *   f = pc + s*(pc - pn);  y += dt[step] * f
+ * pc = pred[b, row_off + i, :], pn = pred[B + b, row_off + i, :]  (pred is (2B, Np, C)).
+ * With apg != NULL (remove_parallel_component): apg[b] = {sum (pc-pn)*pc, sum pc*pc} in
+ * fp64 from v2a_apg_reduce and   upd = orth + keep*par.
+ * Replaces: cfg_transformer_with_pred_head x3:2106-2113, project x3:162-173,
+ * torchdiffeq Euler step (x3:2255).
+ * ------------------------------------------------------------------------------------- */
+int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t T, int32_t C,
+                   int64_t pred_batch_stride, int32_t row_off, v2a_stream_t stream);
+int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C,
+                  int64_t pred_batch_stride, int32_t row_off, float cfg_strength,
+                  const float* dt, const int32_t* step, const double* apg,
+                  float keep_parallel_frac, v2a_stream_t stream);
+/* step[0] += 1 (own launch: every block of the step has read step[0] before it runs) */
+int v2a_step_advance(int32_t* step, v2a_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2A_CFM_H */

@@ -1,0 +1,216 @@
+"""ctypes binding of libv2a_cfm.so (the C ABI declared in include/v2a_cfm.h).
+
+The library is built in-tree by csrc/build.sh (hipcc --offload-arch=gfx950) and loaded
+AFTER `import torch`, so its libamdhip64.so.7 dependency resolves to the HIP runtime torch
+already loaded and torch streams / device pointers are valid in it.  There is no CPU
+fallback: if the library is missing, every op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libv2a_cfm.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_SIGMOID, EPI_GEGLU, EPI_RESID, EPI_GATE_RESID = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class V2AError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p * 3), ("lda", C.c_int64 * 3), ("ka", C.c_int32 * 3),
+        ("nseg", C.c_int32), ("a_dtype", C.c_int32),
+        ("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("compute_dtype", C.c_int32), ("epilogue", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("out_dtype", C.c_int32),
+        ("resid", C.c_void_p), ("ldr", C.c_int64),
+        ("gate", C.c_void_p), ("step", C.c_void_p),
+        ("gate_step_stride", C.c_int64), ("gate_batch_stride", C.c_int64), ("rows_per_batch", C.c_int32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
+        ("q_row_stride", C.c_int64), ("k_row_stride", C.c_int64), ("v_row_stride", C.c_int64),
+        ("gate_row_stride", C.c_int64), ("out_row_stride", C.c_int64),
+        ("q_batch_stride", C.c_int64), ("k_batch_stride", C.c_int64), ("v_batch_stride", C.c_int64),
+        ("gate_batch_stride", C.c_int64), ("out_batch_stride", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32),
+        ("kv_len", C.c_void_p), ("q_len", C.c_void_p),
+        ("scale", C.c_float), ("softclamp", C.c_float), ("dtype", C.c_int32),
+    ]
+
+
+EXPORTS = [
+    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
+    "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
+    "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance",
+]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libv2a_cfm.so (cross-compiles without a GPU)."""
+    if force:
+        for f in os.listdir(os.path.join(CSRC, "build")) if os.path.isdir(os.path.join(CSRC, "build")) else []:
+            os.remove(os.path.join(CSRC, "build", f))
+    r = subprocess.run(["bash", os.path.join(CSRC, "build.sh")], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-8000:])
+    if r.returncode != 0:
+        raise V2AError("hipcc build of libv2a_cfm.so failed")
+    return LIB_PATH
+
+
+def _declare(lib):
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.v2a_abi_version.restype = C.c_int
+    lib.v2a_last_error.restype = C.c_char_p
+    lib.v2a_gemm.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.v2a_attention.argtypes = [C.POINTER(AttnArgs), vp]
+    lib.v2a_rmsnorm.argtypes = [vp, i64, vp, i64, i32, i64, i32, vp, vp, i64, i64, i32, vp]
+    lib.v2a_dwconv_silu_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.v2a_rope_inplace.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, i32, vp]
+    lib.v2a_linear_small.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, vp]
+    lib.v2a_fill_registers.argtypes = [vp, i64, vp, i32, i32, i32, vp]
+    lib.v2a_time_cond.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp]
+    lib.v2a_apg_reduce.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp]
+    lib.v2a_cfg_euler.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, f32, vp]
+    lib.v2a_step_advance.argtypes = [vp, vp]
+    for name in EXPORTS:
+        if name not in ("v2a_abi_version", "v2a_last_error"):
+            getattr(lib, name).restype = C.c_int
+
+
+def lib():
+    """The loaded library; raises loudly if it was never built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise V2AError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the sampler.")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise V2AError(f"v2a_cfm call failed ({rc}): {lib().v2a_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise V2AError(f"unsupported dtype {t}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------
+# thin typed wrappers (torch tensors are only carriers of device pointers here)
+# ------------------------------------------------------------------------------------------
+
+def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
+         step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None):
+    """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
+    g = GemmArgs()
+    for i, (t, lda, k) in enumerate(a_segs):
+        g.a[i] = t.data_ptr()
+        g.lda[i] = lda
+        g.ka[i] = k
+    g.nseg = len(a_segs)
+    g.a_dtype = dt_code(a_segs[0][0].dtype)
+    g.w = w.data_ptr()
+    g.ldw = w.stride(0)
+    g.bias = _p(bias)
+    g.M, g.N = M, N
+    g.compute_dtype = compute
+    g.epilogue = epilogue
+    g.out = out.data_ptr()
+    g.ldo = ldo if ldo is not None else out.stride(-2)
+    g.out_dtype = dt_code(out.dtype)
+    g.resid = _p(resid)
+    g.ldr = (ldr if ldr is not None else (resid.stride(-2) if resid is not None else 0))
+    g.gate = _p(gate)
+    g.step = _p(step)
+    g.gate_step_stride = gate_step_stride
+    g.gate_batch_stride = gate_batch_stride
+    g.rows_per_batch = rows_per_batch
+    check(lib().v2a_gemm(C.byref(g), stream_ptr()))
+
+
+def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch_stride=0, rows_per_batch=0,
+            ldx=None, ldy=None):
+    check(lib().v2a_rmsnorm(x.data_ptr(), ldx or d, y.data_ptr(), ldy or d, dt_code(y.dtype), rows, d,
+                            gamma.data_ptr(), _p(step), gamma_step_stride, gamma_batch_stride, rows_per_batch,
+                            stream_ptr()))
+
+
+def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None):
+    check(lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                         B, N, d, ksize, _p(lens), stream_ptr()))
+
+
+def rope(qk, *, rows, row_stride, nheads, rows_per_batch, pos_offset, table, layout):
+    check(lib().v2a_rope_inplace(qk.data_ptr(), dt_code(qk.dtype), rows, row_stride, nheads, rows_per_batch,
+                                 pos_offset, table.data_ptr(), layout, stream_ptr()))
+
+
+def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype):
+    """q,k,v,gate,out: integer device addresses (views into fused buffers)."""
+    a = AttnArgs()
+    a.q, a.k, a.v, a.gate, a.out = q, k, v, gate, out
+    (a.q_row_stride, a.k_row_stride, a.v_row_stride, a.gate_row_stride, a.out_row_stride,
+     a.q_batch_stride, a.k_batch_stride, a.v_batch_stride, a.gate_batch_stride, a.out_batch_stride) = strides
+    a.B, a.H, a.Nq, a.Nk = B, H, Nq, Nk
+    a.kv_len, a.q_len = _p(kv_len), _p(q_len)
+    a.scale, a.softclamp, a.dtype = scale, softclamp, dtype
+    check(lib().v2a_attention(C.byref(a), stream_ptr()))
+
+
+def linear_small(a, wt, bias, add, out, *, M, K, T, out_batch_stride, row_off, d, dup=0):
+    check(lib().v2a_linear_small(a.data_ptr(), M, K, wt.data_ptr(), _p(bias), _p(add), T, out.data_ptr(),
+                                 out_batch_stride, row_off, d, dup, stream_ptr()))
+
+
+def fill_registers(out, regs, *, B, R, d, out_batch_stride):
+    check(lib().v2a_fill_registers(out.data_ptr(), out_batch_stride, regs.data_ptr(), B, R, d, stream_ptr()))
+
+
+def time_cond(t, fourier_w, wt, bias, out, *, S, d):
+    check(lib().v2a_time_cond(t.data_ptr(), S, fourier_w.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                              out.data_ptr(), d, stream_ptr()))
+
+
+def apg_reduce(pred, apg, *, B, T, C_, pred_batch_stride, row_off):
+    check(lib().v2a_apg_reduce(pred.data_ptr(), apg.data_ptr(), B, T, C_, pred_batch_stride, row_off, stream_ptr()))
+
+
+def cfg_euler(y, pred, *, B, T, C_, pred_batch_stride, row_off, cfg_strength, dt, step=None, apg=None, keep=0.0):
+    check(lib().v2a_cfg_euler(y.data_ptr(), pred.data_ptr(), B, T, C_, pred_batch_stride, row_off,
+                              float(cfg_strength), dt.data_ptr(), _p(step), _p(apg), float(keep), stream_ptr()))
+
+
+def step_advance(step):
+    check(lib().v2a_step_advance(step.data_ptr(), stream_ptr()))

@@ -1,0 +1,428 @@
+// HBM-bound row kernels of the V2A sampler for gfx950: RMSNorm/AdaptiveRMSNorm, depthwise
+// conv + SiLU + residual, rotary embedding, CFG + Euler update, and the small fp32 setup
+// kernels (proj_in / proj_frames scatter, register fill, time conditioning).
+// All loads/stores are 16 B per lane on the channel-contiguous (B, N, d) layout.
+#include "v2a_common.h"
+
+thread_local char v2a_err_buf[512] = {0};
+
+extern "C" int v2a_abi_version(void) { return 1; }
+extern "C" const char* v2a_last_error(void) { return v2a_err_buf; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm: one wave per row; the row (d <= 2048 floats) stays in registers between the
+// sum-of-squares pass and the scale pass, so x is read once: 4*d B in, sizeof(T)*d B out.
+// ------------------------------------------------------------------------------------------
+template <typename OutT, int VPL /* float4 per lane */>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int64_t ldx, OutT* __restrict__ y,
+                                                      int64_t ldy, int64_t rows, int d, const float* gamma,
+                                                      const int32_t* step, int64_t gss, int64_t gbs, int rpb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  const float* g = step_vec(gamma, step, gss, gbs, row / rpb);
+  const int nvec = d >> 2;
+  f32x4 v[VPL];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+      ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+  }
+  ss = wave_sum(ss);
+  // F.normalize: x / max(||x||, eps), eps = 1e-12; then * sqrt(d)
+  const float inv = sqrtf((float)d) / fmaxf(sqrtf(ss), 1e-12f);
+  OutT* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * c);
+      if constexpr (sizeof(OutT) == 4) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[i][j] * inv * gv[j];
+        *reinterpret_cast<f32x4*>(yr + 4 * c) = o;
+      } else {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[i][j] * inv * gv[j]);
+        *reinterpret_cast<bf16x4*>(yr + 4 * c) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Depthwise conv (k taps along N) + bias + SiLU + mask + residual.
+// A thread owns 4 consecutive channels and TN consecutive positions; it streams the
+// TN + k - 1 input rows once (float4 each) and scatters every input into the <= k outputs
+// that use it; the k tap weights (float4 each, [k][d] layout -> coalesced) stay in registers.
+// ------------------------------------------------------------------------------------------
+template <int KS, int TN>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     const float* __restrict__ wt, const float* __restrict__ bias,
+                                                     int B, int N, int d, const int32_t* len) {
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;  // float4 channel group
+  if (c4 * 4 >= d) return;
+  const int n0 = blockIdx.y * TN;
+  const int b = blockIdx.z;
+  const int L = len ? min(len[b], N) : N;
+  constexpr int HALF = KS / 2;
+  f32x4 w[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) w[j] = *reinterpret_cast<const f32x4*>(wt + (int64_t)j * d + 4 * c4);
+  f32x4 acc[TN];
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+#pragma unroll
+  for (int t = 0; t < TN; ++t) acc[t] = bv;
+  const float* xb = x + (int64_t)b * N * d + 4 * c4;
+  // input position p = n0 - HALF + i contributes to output t with tap j = p - (n0 + t) + HALF = i - t
+#pragma unroll
+  for (int i = 0; i < TN + KS - 1; ++i) {
+    const int pos = n0 - HALF + i;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool valid = pos >= 0 && pos < N;
+    if (valid) v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pos * d);
+    if (!(valid && pos < L)) continue;                      // masked input -> zero contribution
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int j = i - t;
+      if (j >= 0 && j < KS) {
+        acc[t][0] += w[j][0] * v[0];
+        acc[t][1] += w[j][1] * v[1];
+        acc[t][2] += w[j][2] * v[2];
+        acc[t][3] += w[j][3] * v[3];
+      }
+    }
+  }
+  float* ob = out + (int64_t)b * N * d + 4 * c4;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = n0 + t;
+    if (n >= N) break;
+    f32x4 o = *reinterpret_cast<const f32x4*>(xb + (int64_t)n * d);  // unmasked x for the residual (L1/L2 hit)
+    if (n < L) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += silu_f(acc[t][j]);
+    }
+    *reinterpret_cast<f32x4*>(ob + (int64_t)n * d) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE in place on nheads x 64 columns of each row.  One thread rotates 4 pairs.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qk, int64_t rows, int64_t row_stride, int nheads,
+                                                   int rpb, int pos_offset, const float* __restrict__ cs, int layout) {
+  // work item = (row, head, quad) with quad in [0, 8): pairs 4*quad .. 4*quad+3
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_row = (int64_t)nheads * 8;
+  if (idx >= rows * per_row) return;
+  const int64_t row = idx / per_row;
+  const int rem = (int)(idx % per_row);
+  const int head = rem >> 3, quad = rem & 7;
+  const int pos = pos_offset + (int)(row % rpb);
+  T* base = qk + row * row_stride + head * 64;
+  const float* c = cs + ((int64_t)pos * 32 + quad * 4) * 2;
+  float a[4], b[4];
+  if (layout == 0) {  // interleaved: pair i = (2i, 2i+1) -> 8 consecutive elements
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = to_f32(base[quad * 8 + 2 * i]);
+      b[i] = to_f32(base[quad * 8 + 2 * i + 1]);
+    }
+  } else {            // half split: pair i = (i, i + 32)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = to_f32(base[quad * 4 + i]);
+      b[i] = to_f32(base[32 + quad * 4 + i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float co = c[2 * i], si = c[2 * i + 1];
+    const float ra = a[i] * co - b[i] * si;   // t*cos + rotate_half(t)*sin, rotate_half = (-x2, x1)
+    const float rb = b[i] * co + a[i] * si;
+    a[i] = ra;
+    b[i] = rb;
+  }
+  if (layout == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      base[quad * 8 + 2 * i] = from_f32<T>(a[i]);
+      base[quad * 8 + 2 * i + 1] = from_f32<T>(b[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      base[quad * 4 + i] = from_f32<T>(a[i]);
+      base[32 + quad * 4 + i] = from_f32<T>(b[i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small fp32 linear with row scatter (proj_in + abs_pos_emb + both CFG halves; proj_frames).
+// Block = 256 threads, ROWS input rows per block staged in LDS; thread n-strided outputs with
+// coalesced wt[k][n] reads.
+// ------------------------------------------------------------------------------------------
+template <int ROWS>
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ a, int64_t M, int K,
+                                                           const float* __restrict__ wt, const float* __restrict__ bias,
+                                                           const float* __restrict__ add, int T, float* __restrict__ out,
+                                                           int64_t obs, int row_off, int d, int dup) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* as = reinterpret_cast<float*>(smem_raw);  // [ROWS][K]
+  const int64_t m0 = (int64_t)blockIdx.x * ROWS;
+  for (int i = threadIdx.x; i < ROWS * K; i += blockDim.x) {
+    const int64_t m = m0 + i / K;
+    as[i] = m < M ? a[m * K + (i % K)] : 0.f;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < d; n += blockDim.x) {
+    float acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float w = wt[(int64_t)k * d + n];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) acc[r] += as[r * K + k] * w;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int64_t m = m0 + r;
+      if (m >= M) break;
+      const int64_t b = m / T;
+      const int i = (int)(m % T);
+      float v = acc[r];
+      if (bias) v += bias[n];
+      if (add) v += add[(int64_t)i * d + n];
+      out[b * obs + (int64_t)(row_off + i) * d + n] = v;
+      if (dup > 0) out[(b + dup) * obs + (int64_t)(row_off + i) * d + n] = v;
+    }
+  }
+}
+
+__global__ void fill_registers_kernel(float* __restrict__ out, int64_t obs, const float* __restrict__ regs, int B, int R,
+                                      int d) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)R * d;
+  if (idx >= per * B) return;
+  const int64_t b = idx / per, r = idx % per;
+  out[b * obs + r] = regs[r];
+}
+
+// time conditioning: one block per grid point
+__global__ __launch_bounds__(256) void time_cond_kernel(const float* __restrict__ t, const float* __restrict__ fw,
+                                                        const float* __restrict__ wt, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int d) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* e = reinterpret_cast<float*>(smem_raw);  // [d + 1]
+  const int s = blockIdx.x;
+  const float ts = t[s];
+  const int half = d / 2;
+  if (threadIdx.x == 0) e[0] = ts;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float f = ts * fw[i] * 2.0f * 3.14159265358979323846f;  // x3:562 order: (t*w)*2*pi
+    e[1 + i] = sinf(f);
+    e[1 + half + i] = cosf(f);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < d; n += blockDim.x) {
+    float acc = bias[n];
+    for (int k = 0; k < d + 1; ++k) acc += e[k] * wt[(int64_t)k * d + n];
+    out[(int64_t)s * d + n] = silu_f(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CFG + Euler.  Algorithmic traffic per element: read pc, pn, y + write y = 16 B.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ y, const float* __restrict__ pred, int B,
+                                                        int T, int C, int64_t pbs, int row_off, float s,
+                                                        const float* __restrict__ dt, const int32_t* step,
+                                                        const double* apg, float keep) {
+  const int64_t idx4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_b = (int64_t)T * C;
+  const int64_t total4 = (int64_t)B * per_b / 4;
+  if (idx4 >= total4) return;
+  const int64_t e = idx4 * 4;
+  const int64_t b = e / per_b, r = e % per_b;
+  const float h = dt[step ? step[0] : 0];
+  const f32x4 pc = *reinterpret_cast<const f32x4*>(pred + b * pbs + (int64_t)row_off * C + r);
+  const f32x4 pn = *reinterpret_cast<const f32x4*>(pred + (b + B) * pbs + (int64_t)row_off * C + r);
+  f32x4 yv = *reinterpret_cast<const f32x4*>(y + e);
+  float coef = 0.f;
+  if (apg) {
+    // parallel = (<upd, pred> / <pred, pred>) * pred  (unit = pred / max(|pred|, 1e-12))
+    const double dot = apg[2 * b], nn = apg[2 * b + 1];
+    const double nrm = sqrt(nn) > 1e-12 ? sqrt(nn) : 1e-12;
+    coef = (float)(dot / (nrm * nrm));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float upd = pc[j] - pn[j];
+    if (apg) {
+      const float par = coef * pc[j];
+      upd = (upd - par) + par * keep;
+    }
+    yv[j] += h * (pc[j] + upd * s);
+  }
+  *reinterpret_cast<f32x4*>(y + e) = yv;
+}
+
+__global__ __launch_bounds__(256) void apg_reduce_kernel(const float* __restrict__ pred, double* __restrict__ apg, int B,
+                                                         int T, int C, int64_t pbs, int row_off) {
+  // grid = (chunks, B); fp64 partial sums, one atomic pair per block
+  const int b = blockIdx.y;
+  const int64_t per_b = (int64_t)T * C;
+  double dot = 0.0, nn = 0.0;
+  const float* pc = pred + (int64_t)b * pbs + (int64_t)row_off * C;
+  const float* pn = pred + (int64_t)(b + B) * pbs + (int64_t)row_off * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_b; i += (int64_t)gridDim.x * blockDim.x) {
+    const double c = pc[i], n = pn[i];
+    dot += (c - n) * c;
+    nn += c * c;
+  }
+  __shared__ double sd[256], sn[256];
+  sd[threadIdx.x] = dot;
+  sn[threadIdx.x] = nn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sd[threadIdx.x] += sd[threadIdx.x + o];
+      sn[threadIdx.x] += sn[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&apg[2 * b], sd[0]);
+    atomicAdd(&apg[2 * b + 1], sn[0]);
+  }
+}
+
+__global__ void step_advance_kernel(int32_t* step) { step[0] += 1; }
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t y_dtype, int64_t rows, int32_t d,
+                           const float* gamma, const int32_t* step, int64_t gss, int64_t gbs, int32_t rpb,
+                           v2a_stream_t stream) {
+  V2A_REQUIRE(x && y && gamma, "v2a_rmsnorm: null pointer");
+  V2A_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 2048, "v2a_rmsnorm: d=%d (need d %% 4 == 0, d <= 2048)", d);
+  V2A_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && gss % 4 == 0 && gbs % 4 == 0, "v2a_rmsnorm: strides must be multiples of 4");
+  V2A_REQUIRE(y_dtype == V2A_F32 || y_dtype == V2A_BF16, "v2a_rmsnorm: y dtype %d", y_dtype);
+  if (rpb <= 0) rpb = (int32_t)rows;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const int vpl = (d / 4 + 63) / 64;
+#define V2A_RMS(OT, V) \
+  hipLaunchKernelGGL((rmsnorm_kernel<OT, V>), grid, block, 0, s, x, ldx, (OT*)y, ldy, rows, d, gamma, step, gss, gbs, rpb)
+  if (y_dtype == V2A_F32) {
+    if (vpl <= 1) V2A_RMS(float, 1); else if (vpl <= 2) V2A_RMS(float, 2); else if (vpl <= 4) V2A_RMS(float, 4); else V2A_RMS(float, 8);
+  } else {
+    if (vpl <= 1) V2A_RMS(bf16_t, 1); else if (vpl <= 2) V2A_RMS(bf16_t, 2); else if (vpl <= 4) V2A_RMS(bf16_t, 4); else V2A_RMS(bf16_t, 8);
+  }
+#undef V2A_RMS
+  return v2a_check_launch("v2a_rmsnorm");
+}
+
+extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias, int32_t B,
+                                        int32_t N, int32_t d, int32_t ksize, const int32_t* len, v2a_stream_t stream) {
+  V2A_REQUIRE(x && out && wt && bias, "v2a_dwconv: null pointer");
+  V2A_REQUIRE(x != out, "v2a_dwconv: out must not alias x (halo reads)");
+  V2A_REQUIRE(ksize == 31, "v2a_dwconv: kernel_size %d (only 31 is built, x3:726)", ksize);
+  V2A_REQUIRE(d % 4 == 0 && B > 0 && N > 0, "v2a_dwconv: B=%d N=%d d=%d", B, N, d);
+  constexpr int TN = 8;
+  const int c4 = d / 4;
+  const int bx = c4 >= 256 ? 256 : ((c4 + 63) / 64) * 64;
+  dim3 grid((c4 + bx - 1) / bx, (N + TN - 1) / TN, B), block(bx);
+  hipLaunchKernelGGL((dwconv_kernel<31, TN>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
+  return v2a_check_launch("v2a_dwconv_silu_residual");
+}
+
+extern "C" int v2a_rope_inplace(void* qk, int32_t dtype, int64_t rows, int64_t row_stride, int32_t nheads,
+                                int32_t rpb, int32_t pos_offset, const float* cs, int32_t layout, v2a_stream_t stream) {
+  V2A_REQUIRE(qk && cs, "v2a_rope: null pointer");
+  V2A_REQUIRE(rows > 0 && nheads > 0 && rpb > 0, "v2a_rope: rows=%lld nheads=%d rpb=%d", (long long)rows, nheads, rpb);
+  V2A_REQUIRE(layout == 0 || layout == 1, "v2a_rope: layout %d", layout);
+  const int64_t total = rows * nheads * 8;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == V2A_F32)
+    hipLaunchKernelGGL((rope_kernel<float>), grid, block, 0, s, (float*)qk, rows, row_stride, nheads, rpb, pos_offset, cs, layout);
+  else if (dtype == V2A_BF16)
+    hipLaunchKernelGGL((rope_kernel<bf16_t>), grid, block, 0, s, (bf16_t*)qk, rows, row_stride, nheads, rpb, pos_offset, cs, layout);
+  else
+    return v2a_fail(V2A_ERR_ARG, "v2a_rope: dtype %d", dtype);
+  return v2a_check_launch("v2a_rope_inplace");
+}
+
+extern "C" int v2a_linear_small(const float* a, int64_t M, int32_t K, const float* wt, const float* bias,
+                                const float* add, int32_t T, float* out, int64_t obs, int32_t row_off, int32_t d,
+                                int32_t dup, v2a_stream_t stream) {
+  V2A_REQUIRE(a && wt && out, "v2a_linear_small: null pointer");
+  V2A_REQUIRE(M > 0 && K > 0 && K <= 2048 && T > 0 && d > 0, "v2a_linear_small: M=%lld K=%d T=%d d=%d", (long long)M, K, T, d);
+  constexpr int ROWS = 4;
+  dim3 grid((unsigned)((M + ROWS - 1) / ROWS)), block(256);
+  hipLaunchKernelGGL((linear_small_kernel<ROWS>), grid, block, ROWS * K * sizeof(float), (hipStream_t)stream, a, M, K, wt,
+                     bias, add, T, out, obs, row_off, d, dup);
+  return v2a_check_launch("v2a_linear_small");
+}
+
+extern "C" int v2a_fill_registers(float* out, int64_t obs, const float* regs, int32_t B, int32_t R, int32_t d,
+                                  v2a_stream_t stream) {
+  V2A_REQUIRE(out && regs && B > 0 && R > 0 && d > 0, "v2a_fill_registers: bad args");
+  const int64_t total = (int64_t)B * R * d;
+  hipLaunchKernelGGL(fill_registers_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     obs, regs, B, R, d);
+  return v2a_check_launch("v2a_fill_registers");
+}
+
+extern "C" int v2a_time_cond(const float* t, int32_t S, const float* fw, const float* wt, const float* bias, float* out,
+                             int32_t d, v2a_stream_t stream) {
+  V2A_REQUIRE(t && fw && wt && bias && out, "v2a_time_cond: null pointer");
+  V2A_REQUIRE(S > 0 && d > 0 && d % 2 == 0, "v2a_time_cond: S=%d d=%d", S, d);
+  hipLaunchKernelGGL(time_cond_kernel, dim3(S), dim3(256), (d + 1) * sizeof(float), (hipStream_t)stream, t, fw, wt, bias,
+                     out, d);
+  return v2a_check_launch("v2a_time_cond");
+}
+
+extern "C" int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t T, int32_t C, int64_t pbs,
+                              int32_t row_off, v2a_stream_t stream) {
+  V2A_REQUIRE(pred && apg && B > 0 && T > 0 && C > 0, "v2a_apg_reduce: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(apg, 0, sizeof(double) * 2 * B, s);
+  if (e != hipSuccess) return v2a_fail(V2A_ERR_LAUNCH, "v2a_apg_reduce memset: %s", hipGetErrorString(e));
+  const int64_t per_b = (int64_t)T * C;
+  int chunks = (int)((per_b + 256 * 8 - 1) / (256 * 8));
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(apg_reduce_kernel, dim3(chunks, B), dim3(256), 0, s, pred, apg, B, T, C, pbs, row_off);
+  return v2a_check_launch("v2a_apg_reduce");
+}
+
+extern "C" int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C, int64_t pbs, int32_t row_off,
+                             float cfg_strength, const float* dt, const int32_t* step, const double* apg, float keep,
+                             v2a_stream_t stream) {
+  V2A_REQUIRE(y && pred && dt, "v2a_cfg_euler: null pointer");
+  V2A_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && pbs % 4 == 0, "v2a_cfg_euler: B=%d T=%d C=%d", B, T, C);
+  const int64_t total4 = (int64_t)B * T * C / 4;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, pred,
+                     B, T, C, pbs, row_off, cfg_strength, dt, step, apg, keep);
+  return v2a_check_launch("v2a_cfg_euler");
+}
+
+extern "C" int v2a_step_advance(int32_t* step, v2a_stream_t stream) {
+  V2A_REQUIRE(step, "v2a_step_advance: null pointer");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+  return v2a_check_launch("v2a_step_advance");
+}

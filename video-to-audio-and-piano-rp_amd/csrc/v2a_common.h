@@ -1,0 +1,69 @@
+// Shared device/host helpers for the gfx950 kernels of the V2A flow-matching sampler.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/v2a_cfm.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define V2A_WAVE 64
+
+// ---- error reporting (host) -------------------------------------------------------------
+extern thread_local char v2a_err_buf[512];
+static inline int v2a_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(v2a_err_buf, sizeof(v2a_err_buf), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define V2A_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return v2a_fail(V2A_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+static inline int v2a_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return v2a_fail(V2A_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return V2A_OK;
+}
+
+// ---- device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// step vector address: base + step[0]*step_stride + batch*batch_stride
+__device__ __forceinline__ const float* step_vec(const float* base, const int32_t* step, int64_t step_stride,
+                                                 int64_t batch_stride, int64_t batch) {
+  int64_t s = step ? (int64_t)step[0] : 0;
+  return base + s * step_stride + batch * batch_stride;
+}
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = V2A_F32; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = V2A_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
