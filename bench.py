@@ -1,0 +1,215 @@
+"""Headline benchmark: mel-frames/sec of the flow-matching V2A sampler (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full sample() of this rank's clip shard: VGGSound 10 s shape (750 latent frames
+x 128 channels), 32-point sway grid = 31 CFG evaluations = 62 forwards of the 776.6 M-parameter
+three-stream DiT, bf16 operands / fp32 accumulate, CFG 2.0 -- BASELINE.json configs[1].  Weights are
+random-init and conditioning is synthetic (no checkpoints or videos exist offline) but of the real
+shapes; they are resident in HBM before the timed region, which covers everything sample() does
+(modulation tables, cross-attention K/V, the Euler loop) plus, for N > 1, the single all-gather
+of latents.  Ranks are clip-sharded (weak scaling, no per-step communication).
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries
+  roofline     : the dominant kernel (bf16 MFMA GEMM instantiation with the most time), measured
+                 with HIP events on the launch stream over an eager replay of one Euler evaluation;
+  cpu_baseline : the CPU restatement of the reference (oracle/, "port") timed on this box's host
+                 cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5, help="timed sample() calls")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips-per-gpu", type=int, default=1, help="configs[1] is one 10 s clip; configs[2] uses 8")
+    ap.add_argument("--cfm-steps", type=int, default=32)
+    ap.add_argument("--cfg-strength", type=float, default=2.0)
+    ap.add_argument("--frames", type=int, default=750)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--v2p", action="store_true", help="configs[3]: non-zero piano roll, 64 steps")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="grid points of the bounded CPU sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import v2a_amd
+    from v2a_amd import _lib as L
+    from v2a_amd.synth import random_state_dict, synthetic_conditioning
+
+    cfg = v2a_amd.DiTConfig()
+    B, T, NC = args.clips_per_gpu, args.frames, 16
+    cfm_steps = 64 if args.v2p and args.cfm_steps == 32 else args.cfm_steps
+    sd = random_state_dict(cfg, seed=0, device=dev)
+    model = v2a_amd.E2TTS(transformer=dict(depth=cfg.depth, dim=cfg.dim, dim_text=cfg.dim_text, heads=cfg.heads, dim_head=cfg.dim_head,
+                                           if_text_modules=True, if_cross_attn=True, if_audio_conv=True, if_text_conv=True),
+                          num_channels=cfg.num_channels, sampling_rate=24000, if_cond_proj_in=False, tokenizer="phoneme_zh",
+                          compute_dtype=args.dtype, device=dev, use_graph=not args.no_graph)
+    model.load_state_dict(sd, strict=False)
+    del sd
+    y0, text, roll, ctx, cm = synthetic_conditioning(cfg, B, T, NC, seed=1000 + rank, piano=args.v2p, device=dev)
+    cm = cm.cpu()
+    cond = torch.empty(B, T, cfg.num_channels, device=dev)      # placeholder, as predict.py:261
+    lens = torch.full((B,), T, dtype=torch.long)
+    n_clips = B * world
+
+    def one_step(steps=cfm_steps):
+        out = model.sample(cond, y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, lens=lens,
+                           duration=lens, steps=steps, cfg_strength=args.cfg_strength, remove_parallel_component=False,
+                           sway_sampling=True, return_raw_output=True)
+        return v2a_amd.gather_latents(out, n_clips, B)
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert out.shape == (n_clips, T, cfg.num_channels) and bool(torch.isfinite(out).all())
+
+    ms_per_step = el / args.steps * 1e3
+    frames_per_s = n_clips * T / (el / args.steps)
+    evals = cfm_steps - 1
+    # algorithmic work per forward per clip at this shape (1040.7 GFLOP GEMM + 75.8 attention)
+    res = {
+        "metric": "mel-frames/sec (10s VGGSound shape, %d-step CFM, CFG %.1f)" % (cfm_steps, args.cfg_strength),
+        "value": round(frames_per_s, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[%d]: %d clip(s)/GPU x %d latent frames x 128 ch, %d-point sway grid = %d CFG "
+                               "evaluations (%d DiT forwards), T5 context %d tokens, %s"
+                               % (3 if args.v2p else 1, B, T, cfm_steps, evals, 2 * evals, NC, "V2P roll" if args.v2p else "V2A zero roll"),
+                   "clips_per_gpu": B, "global_clips": n_clips, "parallelism": "clip-sharded x%d, 1 all-gather" % world,
+                   "hipgraph": not args.no_graph},
+        "per_gpu_mel_frames_per_s": round(frames_per_s / world, 2),
+        "clips_per_s": round(n_clips / (el / args.steps), 4),
+        "ms_per_cfg_evaluation": round(ms_per_step / evals, 4),
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            res["roofline"] = roofline_leg(model, L, y0, args)
+        if not args.no_cpu_baseline:
+            res.update(cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T))
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_leg(model, L, y0, args):
+    """Eager replay of Euler evaluations with every launch bracketed by HIP events on the launch
+    stream.  `achieved` = algorithmic FLOPs (2*M*N*K per launch) / event-measured kernel time for the
+    GEMM instantiation that takes the most time in a step; the per-kernel table is attached."""
+    eng = model.engine()
+    p = eng.plan
+    y = p["y"]
+    reps = 3
+    prof = L.KernelProfiler()
+    keep = y.clone()
+    # warm: one untimed eager evaluation
+    p["step"].zero_()
+    eng.euler_step(y, args.cfg_strength, False)
+    L.set_profiler(prof)
+    try:
+        for _ in range(reps):
+            p["step"].zero_()
+            eng.euler_step(y, args.cfg_strength, False)
+    finally:
+        L.set_profiler(None)
+    agg = prof.summary()
+    y.copy_(keep)
+    p["step"].zero_()
+    table, tot_ms = {}, sum(a["ms"] for a in agg.values())
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        row = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
+               "share": round(a["ms"] / tot_ms, 4)}
+        if a["flops"] > 0 and k.startswith("gemm"):
+            row["tflops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2)
+        else:
+            row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
+        table[k] = row
+    gem = [(k, a) for k, a in agg.items() if k.startswith("gemm")]
+    dom_k, dom = max(gem, key=lambda kv: kv[1]["ms"])
+    peak = PEAK_BF16_TFLOPS if "bf16" in dom_k.split(",")[0] else PEAK_F32_TFLOPS
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    all_f = sum(a["flops"] for _, a in gem)
+    all_ms = sum(a["ms"] for _, a in gem)
+    return {"bound": "mfma", "kernel": dom_k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None,
+            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2), "launches_per_eval": dom["launches"] // reps,
+            "all_gemm_tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(all_f / (all_ms * 1e-3) / 1e12 / peak, 4),
+            "eager_eval_kernel_ms": round(tot_ms / reps, 3), "kernels": table}
+
+
+def cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T):
+    """CPU restatement of the reference (oracle/, kind "port"; the reference itself cannot be
+    imported here) on a bounded sample: B=1, `cpu-baseline-steps` grid points, all host
+    cores, linearly extrapolated to the 31 evaluations of the headline (stated in `sample`)."""
+    from oracle import e2_cfm_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = model.state_dict()
+    ocfg = O.DiTConfig()
+    s = args.cpu_baseline_steps
+    a = [t[:1].float().cpu() for t in (y0, text, roll, ctx)]
+    t0 = time.perf_counter()
+    ref = O.sample(P, ocfg, a[0], a[1], a[2], a[3], cm[:1], steps=s, cfg_strength=args.cfg_strength, remove_parallel_component=False)
+    cpu_s = time.perf_counter() - t0
+    per_eval = cpu_s / (s - 1)
+    full = per_eval * (32 - 1)
+    # parity of the measured (bf16 or fp32) GPU path on the same bounded sample
+    got = one_step(steps=s)[:1].float().cpu()
+    err = (got - ref).abs()
+    return {"cpu_baseline": {"value": round(T / full, 3), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                             "sample": "B=1, %d-point grid (%d of 31 CFG evaluations, %.1f s CPU), extrapolated linearly in evaluations; "
+                                       "CPU restatement of the reference in plain torch fp32" % (s, s - 1, cpu_s),
+                             "s_per_cfg_evaluation": round(per_eval, 3)},
+            "parity": {"mode": args.dtype, "sample": "same %d-point grid, B=1" % s, "max_abs_delta_mel": round(float(err.max()), 6),
+                       "mean_abs_delta_mel": round(float(err.mean()), 7)}}
+
+
+if __name__ == "__main__":
+    main()

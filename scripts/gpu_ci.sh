@@ -1,0 +1,32 @@
+#!/bin/bash
+# Runs the given steps on the GPU box one after another; a step that times out (rc 124/137) ends the
+# run (no further GPU step after a hang).  Each step logs to gpurun_out/<name>.log.
+# usage: scripts/gpu_ci.sh step1 step2 ...   with steps from: kernels sampler full smoke bench bench_fp32 prof pmc
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+run() {  # name timeout cmd...
+  local name=$1 to=$2; shift 2
+  echo "=== $name: $*"
+  timeout -k 10 $to "$@" > gpurun_out/$name.log 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc"; tail -n ${TAILN:-15} gpurun_out/$name.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping"; exit 99; fi
+  return $rc
+}
+for s in "$@"; do
+  case $s in
+    kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x --tb=short ;;
+    kernels_all) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=line ;;
+    sampler) run sampler 600 python -m pytest tests/test_sampler_gpu.py -q -m gpu -x --tb=short -s ;;
+    sampler_all) run sampler 600 python -m pytest tests/test_sampler_gpu.py -q -m gpu --tb=short -s ;;
+    full) run full 900 python -m pytest tests/test_full_shape_gpu.py -q -m gpu -x --tb=short -s ;;
+    alltests) run alltests 1100 python -m pytest tests -q -m gpu -x --tb=short ;;
+    smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench) run bench 900 python bench.py --steps 3 --warmup 1 ;;
+    bench_nocpu) run bench_nocpu 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    bench8) run bench8 600 python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline ;;
+    prof) rm -rf gpurun_out/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
+exit 0

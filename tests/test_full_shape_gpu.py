@@ -1,0 +1,69 @@
+"""GPU parity at BASELINE.json's full shape (depth 12, dim 1024/1280/512, T=750, nc=16; 776.6 M params):
+one fp32-mode forward against the CPU oracle run on the same box, the committed full-shape
+statistics, and size-independent properties of the sampler (CFG algebra, batch independence)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import e2_cfm_oracle as O
+from conftest import make_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    cfg = O.DiTConfig()
+    P = O.init_params(cfg, 0)
+    y0, text, roll, ctx, cm = O.synthetic_inputs(cfg, 1, 750, nc=16, seed=0)
+    return dict(cfg=cfg, P=P, y0=y0, text=text, roll=roll, ctx=ctx, cm=cm)
+
+
+def test_full_forward_fp32_vs_oracle_and_stats(full, golden):
+    f = full
+    with torch.no_grad():
+        ref = O.transformer_with_pred_head(f["P"], f["cfg"], f["y0"], torch.tensor(0.37), None, f["text"], f["roll"], f["ctx"], f["cm"],
+                                           drop_text_cond=False, drop_text_prompt=False)
+    st = golden["full_stats"]
+    assert abs(float(ref.std()) - st["std"]) < 1e-3 and np.allclose(ref[0, 0, :8].numpy(), st["first8"], atol=1e-3)
+    m = make_model(f["cfg"], f["P"], "fp32")
+    got = m.transformer_with_pred_head(f["y0"], times=torch.tensor(0.37), text=f["text"], frames_embed=f["roll"], context=f["ctx"],
+                                       context_mask=f["cm"], drop_text_cond=False, drop_text_prompt=False)
+    err = float((got - ref).abs().max())
+    print(f"full-shape fp32 forward: max |delta| = {err:.3e}")
+    assert err < 1e-3
+    full["model_fp32"] = m
+
+
+def test_full_sample_steps4_fp32_vs_oracle(full):
+    """configs[0]-shaped plumbing case on the GPU: steps=4 (3 evaluations, 6 forwards), CFG 2.0."""
+    f = full
+    m = full.get("model_fp32") or make_model(f["cfg"], f["P"], "fp32")
+    kw = dict(steps=4, cfg_strength=2.0, remove_parallel_component=False)
+    ref = O.sample(f["P"], f["cfg"], f["y0"], f["text"], f["roll"], f["ctx"], f["cm"], **kw)
+    got = m.sample(torch.zeros(1, 750, 128), y0=f["y0"], text_embed=f["text"], context=f["ctx"], context_mask=f["cm"],
+                   frames_embed=f["roll"], return_raw_output=True, **kw)
+    err = float((got - ref).abs().max())
+    print(f"full-shape fp32 4-step sample: max |delta mel| = {err:.3e}")
+    assert err < 1e-3
+    # CFG algebra: strength 0 == the conditional pass alone (null half weight 0), x3:2101-2113
+    g0 = m.sample(torch.zeros(1, 750, 128), y0=f["y0"], text_embed=f["text"], context=f["ctx"], context_mask=f["cm"],
+                  frames_embed=f["roll"], return_raw_output=True, steps=2, cfg_strength=0.0, remove_parallel_component=False)
+    pc = m.transformer_with_pred_head(f["y0"], times=torch.tensor(0.0), text=f["text"], frames_embed=f["roll"], context=f["ctx"],
+                                      context_mask=f["cm"], drop_text_cond=False, drop_text_prompt=False)
+    t = O.sway_grid(2)
+    assert float((g0 - (f["y0"] + (t[1] - t[0]) * pc)).abs().max()) < 1e-4
+    del m
+
+
+def test_full_bf16_error_report(full):
+    f = full
+    ref = O.sample(f["P"], f["cfg"], f["y0"], f["text"], f["roll"], f["ctx"], f["cm"], steps=4, cfg_strength=2.0,
+                   remove_parallel_component=False)
+    m = make_model(f["cfg"], f["P"], "bf16")
+    got = m.sample(torch.zeros(1, 750, 128), y0=f["y0"], text_embed=f["text"], context=f["ctx"], context_mask=f["cm"],
+                   frames_embed=f["roll"], return_raw_output=True, steps=4, cfg_strength=2.0, remove_parallel_component=False)
+    err = (got - ref).abs()
+    print(f"full-shape bf16 4-step sample: max |delta mel| = {float(err.max()):.4f}, mean = {float(err.mean()):.5f}")
+    assert float(err.mean()) < 0.05

@@ -1,0 +1,357 @@
+"""GPU parity, kernel by kernel, through the C ABI (v2a_amd._lib -> libv2a_cfm.so), against the
+CPU oracle on seeded inputs and against tests/golden/blocks_small.npz.
+Tolerances: fp32 kernels 1e-5 abs on O(1) values (fp32 summation-order noise only);
+bf16 kernels are checked against the oracle run on bf16-rounded operands (tolerance in each test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import e2_cfm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from v2a_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def _g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------- rmsnorm
+@pytest.mark.parametrize("d", [64, 192, 512, 1024, 1280])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_rmsnorm_plain(L, d, odt):
+    rows = 37
+    x = torch.randn(rows, d, generator=_g(d))
+    g = 1 + 0.1 * torch.randn(d, generator=_g(d + 1))
+    ref = O.rmsnorm(x, g)
+    y = torch.empty(rows, d, dtype=odt, device=DEV)
+    L.rmsnorm(x.to(DEV), y, rows=rows, d=d, gamma=g.to(DEV))
+    tol = 1e-5 if odt == torch.float32 else 2e-2
+    torch.testing.assert_close(y.float().cpu(), ref, atol=tol, rtol=tol)
+
+
+def test_rmsnorm_zero_row_and_step_vector(L):
+    """eps path of F.normalize (all-zero row -> 0) and the step/batch-indexed gamma table."""
+    B, N, d, S = 2, 5, 128, 3
+    x = torch.randn(B * N, d, generator=_g(3))
+    x[4] = 0
+    tab = torch.randn(S, B, d, generator=_g(4))
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    y = torch.empty(B * N, d, device=DEV)
+    L.rmsnorm(x.to(DEV), y, rows=B * N, d=d, gamma=tab.to(DEV), step=step, gamma_step_stride=B * d,
+              gamma_batch_stride=d, rows_per_batch=N)
+    ref = torch.cat([O.rmsnorm(x[b * N:(b + 1) * N], tab[2, b]) for b in range(B)])
+    torch.testing.assert_close(y.cpu(), ref, atol=1e-5, rtol=1e-5)
+    assert float(y[4].abs().max()) == 0.0
+
+
+def test_adaptive_rmsnorm_golden(L, small, golden):
+    b = golden["blocks_small"]
+    P = small["P"]
+    x, c = torch.from_numpy(b["x"]), torch.from_numpy(b["c"])
+    gamma = torch.nn.functional.linear(c, P["transformer.layers.0.0.2.to_gamma.weight"]) + 1.0     # (2, 128)
+    y = torch.empty(2 * 44, 128, device=DEV)
+    L.rmsnorm(x.reshape(-1, 128).to(DEV), y, rows=88, d=128, gamma=gamma.to(DEV), gamma_batch_stride=128, rows_per_batch=44)
+    np.testing.assert_allclose(y.cpu().numpy().reshape(2, 44, 128), b["ada_rmsnorm"], atol=1e-5)
+
+
+# -------------------------------------------------------------------------------- dwconv
+@pytest.mark.parametrize("N,d,lens", [(44, 128, [44, 30]), (782, 512, None), (7, 64, [7, 3]), (100, 1280, [100, 33])])
+def test_dwconv(L, N, d, lens):
+    B = 2
+    x = torch.randn(B, N, d, generator=_g(N))
+    w = torch.randn(d, 1, 31, generator=_g(N + 1)) / math.sqrt(31)
+    bias = 0.1 * torch.randn(d, generator=_g(N + 2))
+    mask = None if lens is None else O.lens_to_mask(torch.tensor(lens), N)
+    ref = O.depthwise_conv(x, w, bias, mask) + x
+    out = torch.empty(B, N, d, device=DEV)
+    ld = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=DEV)
+    L.dwconv(x.to(DEV), out, w[:, 0, :].t().contiguous().to(DEV), bias.to(DEV), B=B, N=N, d=d, ksize=31, lens=ld)
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+def test_dwconv_golden(L, small, golden):
+    b, P = golden["blocks_small"], small["P"]
+    x = torch.from_numpy(b["x"])
+    w, bias = P["transformer.layers.0.0.1.dw_conv1d.0.weight"], P["transformer.layers.0.0.1.dw_conv1d.0.bias"]
+    out = torch.empty(2, 44, 128, device=DEV)
+    L.dwconv(x.to(DEV), out, w[:, 0, :].t().contiguous().to(DEV), bias.to(DEV), B=2, N=44, d=128, ksize=31,
+             lens=torch.tensor([44, 30], dtype=torch.int32, device=DEV))
+    np.testing.assert_allclose((out.cpu() - x).numpy(), b["dwconv"], atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------- rope
+def _rope_table(n):
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(n).float()[:, None] * inv[None, :]
+    return torch.stack((ang.cos(), ang.sin()), -1).contiguous()
+
+
+@pytest.mark.parametrize("layout", ["interleaved", "half"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_rope(L, golden, layout, dt):
+    b = golden["blocks_small"]
+    q = torch.from_numpy(b["rope_in"])                        # (1, 2, 44, 64)
+    rows = q.permute(0, 2, 1, 3).reshape(44, 128).contiguous()
+    pad = torch.zeros(44, 144)
+    pad[:, :128] = rows
+    buf = pad.to(DEV, dt)
+    L.rope(buf, rows=44, row_stride=144, nheads=2, rows_per_batch=44, pos_offset=0, table=_rope_table(44).to(DEV),
+           layout={"interleaved": 0, "half": 1}[layout])
+    got = buf.float().cpu()[:, :128].reshape(1, 44, 2, 64).permute(0, 2, 1, 3)
+    if dt == torch.float32:
+        np.testing.assert_allclose(got.numpy(), b[f"rope_{layout}"], atol=1e-5)
+    else:
+        ref = O.apply_rope(q.bfloat16().float(), O.rotary_freqs(44, 64, layout), layout)
+        torch.testing.assert_close(got, ref, atol=3e-2, rtol=2e-2)
+    assert float(buf[:, 128:].abs().max()) == 0.0              # columns beyond the heads untouched
+
+
+def test_rope_last_rows_offset(L, golden):
+    """A7: cross-attention keys take the LAST nc rows of the table."""
+    b = golden["blocks_small"]
+    q = torch.from_numpy(b["rope_in"])[:, :, :5]               # 5 keys
+    rows = q.permute(0, 2, 1, 3).reshape(5, 128).contiguous().to(DEV)
+    L.rope(rows, rows=5, row_stride=128, nheads=2, rows_per_batch=5, pos_offset=44 - 5, table=_rope_table(44).to(DEV), layout=0)
+    got = rows.cpu().reshape(1, 5, 2, 64).permute(0, 2, 1, 3)
+    np.testing.assert_allclose(got.numpy(), b["rope_last5_interleaved"], atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------- gemm
+def _gemm_ref(a, w, bias):
+    out = a.double() @ w.double().t()
+    if bias is not None:
+        out = out + bias.double()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 144, 64), (1564, 272, 128), (31, 1024, 192), (130, 16, 1024)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gemm_store(L, M, N, K, mode):
+    a = torch.randn(M, K, generator=_g(M))
+    w = torch.randn(N, K, generator=_g(N)) / math.sqrt(K)
+    bias = torch.randn(N, generator=_g(K))
+    if mode == "fp32":
+        out = torch.empty(M, N, device=DEV)
+        L.gemm([(a.to(DEV), K, K)], w.to(DEV), out, M=M, N=N, compute=L.F32, bias=bias.to(DEV))
+        torch.testing.assert_close(out.cpu().double(), _gemm_ref(a, w, bias), atol=2e-5, rtol=1e-5)
+    else:
+        ab, wb = a.bfloat16(), w.bfloat16()
+        ref = _gemm_ref(ab.float(), wb.float(), bias)
+        for odt in (torch.float32, torch.bfloat16):
+            out = torch.empty(M, N, dtype=odt, device=DEV)
+            L.gemm([(ab.to(DEV), K, K)], wb.to(DEV), out, M=M, N=N, compute=L.BF16, bias=bias.to(DEV))
+            tol = 1e-4 if odt == torch.float32 else 2e-2       # fp32 accumulate of exact bf16 products
+            torch.testing.assert_close(out.cpu().double(), ref, atol=tol, rtol=tol)
+        # fp32 A converted on load must equal pre-rounded bf16 A
+        out2 = torch.empty(M, N, device=DEV)
+        L.gemm([(a.to(DEV), K, K)], wb.to(DEV), out2, M=M, N=N, compute=L.BF16, bias=bias.to(DEV))
+        torch.testing.assert_close(out2.cpu().double(), ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gemm_three_segments_resid(L, mode):
+    """concat-free TextAudioCrossCondition: W [N][Ka+Kb+Kc] against three fp32 row-major streams."""
+    M, N, ks = 150, 128, (128, 192, 64)
+    segs = [torch.randn(M, k, generator=_g(k)) for k in ks]
+    w = torch.randn(N, sum(ks), generator=_g(5)) / math.sqrt(sum(ks))
+    resid = torch.randn(M, N, generator=_g(6))
+    cat = torch.cat(segs, -1)
+    cd, comp, tol = (torch.float32, L.F32, 2e-5) if mode == "fp32" else (torch.bfloat16, L.BF16, 1e-4)
+    if mode == "bf16":
+        cat, w = cat.bfloat16().float(), w.bfloat16().float()
+    ref = resid.double() + cat.double() @ w.double().t()
+    out = torch.empty(M, N, device=DEV)
+    L.gemm([(s.to(DEV), s.shape[1], s.shape[1]) for s in segs], w.to(DEV, cd), out, M=M, N=N, compute=comp,
+           epilogue=L.EPI_RESID, resid=resid.to(DEV))
+    torch.testing.assert_close(out.cpu().double(), ref, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gemm_geglu(L, mode):
+    """A8 with the [16 value | 16 gate] row packing of dit._FF."""
+    from v2a_amd.dit import _FF
+    M, d = 100, 128
+    sd = {"ff.ff.0.proj.weight": torch.randn(8 * d, d, generator=_g(1)) / math.sqrt(d), "ff.ff.0.proj.bias": 0.1 * torch.randn(8 * d, generator=_g(2)),
+          "ff.ff.2.weight": torch.randn(d, 4 * d, generator=_g(3)) / math.sqrt(4 * d), "ff.ff.2.bias": 0.1 * torch.randn(d, generator=_g(4))}
+    cd, comp = (torch.float32, L.F32) if mode == "fp32" else (torch.bfloat16, L.BF16)
+    F = _FF(sd, "ff", d, cd, DEV)
+    x = torch.randn(M, d, generator=_g(5))
+    xq = x.to(cd).float()
+    w1 = sd["ff.ff.0.proj.weight"].to(cd).float()
+    h = torch.nn.functional.linear(xq, w1, sd["ff.ff.0.proj.bias"])
+    a, g = h.chunk(2, -1)
+    ref = a * torch.nn.functional.gelu(g)
+    out = torch.empty(M, 4 * d, dtype=cd, device=DEV)
+    L.gemm([(x.to(DEV, cd), d, d)], F.w1, out, M=M, N=8 * d, compute=comp, epilogue=L.EPI_GEGLU, bias=F.b1, ldo=4 * d)
+    tol = 2e-5 if mode == "fp32" else 2e-2
+    torch.testing.assert_close(out.float().cpu(), ref, atol=tol, rtol=tol)
+
+
+def test_gemm_gate_resid_and_sigmoid(L):
+    """AdaLNZero: table = sigmoid(W c + b) (SIGMOID epilogue), then x + gate * (acc + bias) indexed by a device step."""
+    S, d, M, N, K, rpb = 3, 128, 90, 128, 64, 45
+    c = torch.randn(S, d, generator=_g(1))
+    wg, bg = torch.randn(N, d, generator=_g(2)) / math.sqrt(d), torch.randn(N, generator=_g(3))
+    tab = torch.empty(S, N, device=DEV)
+    L.gemm([(c.to(DEV), d, d)], wg.to(DEV), tab, M=S, N=N, compute=L.F32, epilogue=L.EPI_SIGMOID, bias=bg.to(DEV))
+    tab_ref = torch.sigmoid(torch.nn.functional.linear(c, wg, bg))
+    torch.testing.assert_close(tab.cpu(), tab_ref, atol=1e-5, rtol=1e-5)
+    a, w = torch.randn(M, K, generator=_g(4)), torch.randn(N, K, generator=_g(5)) / math.sqrt(K)
+    bias, x = torch.randn(N, generator=_g(6)), torch.randn(M, N, generator=_g(7))
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)
+    xd = x.to(DEV)
+    L.gemm([(a.to(DEV), K, K)], w.to(DEV), xd, M=M, N=N, compute=L.F32, epilogue=L.EPI_GATE_RESID, bias=bias.to(DEV),
+           resid=xd, gate=tab, step=step, gate_step_stride=N, rows_per_batch=rpb)
+    ref = x + tab_ref[1] * torch.nn.functional.linear(a, w, bias)
+    torch.testing.assert_close(xd.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+def test_gemm_rejects_bad_args(L):
+    a = torch.zeros(4, 40, device=DEV)
+    w = torch.zeros(16, 40, device=DEV)
+    out = torch.zeros(4, 16, device=DEV)
+    with pytest.raises(L.V2AError, match="not a multiple"):
+        L.gemm([(a, 40, 40)], w, out, M=4, N=16, compute=L.F32)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, gate, kv_len, q_len, clamp=50.0):
+    """q (B,H,Nq,64) etc. fp32 CPU."""
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * 0.125
+    sim = torch.tanh(sim / clamp) * clamp
+    Nk = k.shape[2]
+    km = torch.arange(Nk)[None, :] < torch.tensor(kv_len)[:, None]
+    sim = sim.masked_fill(~km[:, None, None, :], -torch.finfo(torch.float32).max)
+    out = sim.softmax(-1) @ v
+    out = out * torch.sigmoid(gate)[..., None]
+    qm = torch.arange(q.shape[2])[None, :] < torch.tensor(q_len)[:, None]
+    return out * qm[:, None, :, None]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk,kv_len,q_len", [(2, 2, 44, 44, [44, 30], [44, 30]), (1, 16, 782, 782, [782], [782]),
+                                                  (2, 3, 100, 5, [5, 3], [100, 70]), (1, 1, 65, 129, [129], [65])])
+def test_attention(L, dt, B, H, Nq, Nk, kv_len, q_len):
+    g = _g(Nq + Nk)
+    q = torch.randn(B, H, Nq, 64, generator=g) * 2.0          # |logits| large enough that the tanh clamp bends them
+    k = torch.randn(B, H, Nk, 64, generator=g) * 2.0
+    v = torch.randn(B, H, Nk, 64, generator=g)
+    gate = torch.randn(B, H, Nq, generator=g)
+    q, k, v, gate = (t.to(dt).float() for t in (q, k, v, gate))
+    ref = _attn_ref(q, k, v, gate, kv_len, q_len)
+    # pack as the engine does: rows = tokens, [q | k | v | gate] columns (self) -- here separate buffers with paddings
+    inner = H * 64
+    qb = torch.zeros(B, Nq, inner + 16)
+    qb[..., :inner] = q.permute(0, 2, 1, 3).reshape(B, Nq, inner)
+    qb[..., inner:inner + H] = gate.permute(0, 2, 1)
+    kvb = torch.cat([k.permute(0, 2, 1, 3).reshape(B, Nk, inner), v.permute(0, 2, 1, 3).reshape(B, Nk, inner)], -1)
+    qd, kvd = qb.to(DEV, dt).contiguous(), kvb.to(DEV, dt).contiguous()
+    out = torch.full((B, Nq, inner), float("nan"), dtype=dt, device=DEV)
+    es = qd.element_size()
+    L.attention(qd.data_ptr(), kvd.data_ptr(), kvd.data_ptr() + inner * es, qd.data_ptr() + inner * es, out.data_ptr(),
+                strides=(inner + 16, 2 * inner, 2 * inner, inner + 16, inner,
+                         Nq * (inner + 16), Nk * 2 * inner, Nk * 2 * inner, Nq * (inner + 16), Nq * inner),
+                B=B, H=H, Nq=Nq, Nk=Nk, kv_len=torch.tensor(kv_len, dtype=torch.int32, device=DEV),
+                q_len=torch.tensor(q_len, dtype=torch.int32, device=DEV), scale=0.125, softclamp=50.0,
+                dtype=L.dt_code(dt))
+    got = out.float().cpu().reshape(B, Nq, H, 64).permute(0, 2, 1, 3)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
+
+
+def test_attention_golden_self_and_cross(L, small, golden):
+    """Full Attention module (Linears via v2a_gemm, rope, core) against blocks_small.npz."""
+    from v2a_amd.dit import _Attn
+    b, P, cfg = golden["blocks_small"], small["P"], small["cfg"]
+    x = torch.from_numpy(b["x"])
+    N, d, H = 44, 128, 2
+    lens = torch.tensor([44, 30], dtype=torch.int32, device=DEV)
+    tab = _rope_table(N).to(DEV)
+    for name, cross in (("self_attn", False), ("cross_attn", True)):
+        pre = "transformer.layers.0.0.6" if cross else "transformer.layers.0.0.3"
+        A = _Attn(P, pre, d, H, 64, torch.float32, DEV, cross=cross)
+        xd = x.reshape(-1, d).to(DEV)
+        qkv = torch.empty(2 * N, A.n_pad, device=DEV)
+        L.gemm([(xd, d, d)], A.w_in, qkv, M=2 * N, N=A.n_pad, compute=L.F32, bias=A.b_in)
+        L.rope(qkv, rows=2 * N, row_stride=A.n_pad, nheads=(1 if cross else 2) * H, rows_per_batch=N, pos_offset=0, table=tab, layout=0)
+        ao = torch.empty(2 * N, 128, device=DEV)
+        if cross:
+            ctx = torch.from_numpy(b["ctx"]).reshape(-1, d).to(DEV)
+            wkv = torch.cat([P[f"{pre}.to_k.weight"], P[f"{pre}.to_v.weight"]], 0).to(DEV)
+            kv = torch.empty(10, 256, device=DEV)
+            L.gemm([(ctx, d, d)], wkv, kv, M=10, N=256, compute=L.F32)
+            L.rope(kv, rows=10, row_stride=256, nheads=H, rows_per_batch=5, pos_offset=N - 5, table=tab, layout=0)
+            L.attention(qkv.data_ptr(), kv.data_ptr(), kv.data_ptr() + 128 * 4, qkv.data_ptr() + A.gate_col * 4, ao.data_ptr(),
+                        strides=(A.n_pad, 256, 256, A.n_pad, 128, N * A.n_pad, 5 * 256, 5 * 256, N * A.n_pad, N * 128),
+                        B=2, H=H, Nq=N, Nk=5, kv_len=torch.tensor([5, 3], dtype=torch.int32, device=DEV), q_len=lens,
+                        scale=0.125, softclamp=50.0, dtype=L.F32)
+        else:
+            base = qkv.data_ptr()
+            L.attention(base, base + 128 * 4, base + 256 * 4, base + A.gate_col * 4, ao.data_ptr(),
+                        strides=(A.n_pad,) * 4 + (128,) + (N * A.n_pad,) * 4 + (N * 128,),
+                        B=2, H=H, Nq=N, Nk=N, kv_len=lens, q_len=lens, scale=0.125, softclamp=50.0, dtype=L.F32)
+        out = torch.empty(2 * N, d, device=DEV)
+        L.gemm([(ao, 128, 128)], A.w_out, out, M=2 * N, N=d, compute=L.F32)
+        np.testing.assert_allclose(out.cpu().numpy().reshape(2, N, d), b[name], atol=3e-5)
+
+
+# -------------------------------------------------------------------- small setup kernels
+def test_time_cond_golden(L, small, golden):
+    P, b = small["P"], golden["blocks_small"]
+    t = torch.tensor([0.0, 0.37, 1.0], device=DEV)
+    out = torch.empty(3, 128, device=DEV)
+    L.time_cond(t, P["transformer.time_cond_mlp.0.weights"].to(DEV), P["transformer.time_cond_mlp.1.weight"].t().contiguous().to(DEV),
+                P["transformer.time_cond_mlp.1.bias"].to(DEV), out, S=3, d=128)
+    np.testing.assert_allclose(out.cpu().numpy(), b["time_cond"], atol=2e-5)
+
+
+def test_linear_small_scatter_and_registers(L):
+    B, T, K, d, R = 2, 9, 51, 64, 4
+    a = torch.randn(B * T, K, generator=_g(1))
+    w, bias, add = torch.randn(d, K, generator=_g(2)), torch.randn(d, generator=_g(3)), torch.randn(T, d, generator=_g(4))
+    regs = torch.randn(R, d, generator=_g(5))
+    out = torch.zeros(2 * B, R + T, d, device=DEV)
+    L.fill_registers(out, regs.to(DEV), B=2 * B, R=R, d=d, out_batch_stride=(R + T) * d)
+    L.linear_small(a.to(DEV), w.t().contiguous().to(DEV), bias.to(DEV), add.to(DEV), out, M=B * T, K=K, T=T,
+                   out_batch_stride=(R + T) * d, row_off=R, d=d, dup=B)
+    ref = (torch.nn.functional.linear(a, w, bias).reshape(B, T, d) + add[None])
+    o = out.cpu()
+    for half in (0, B):
+        torch.testing.assert_close(o[half:half + B, R:], ref, atol=2e-5, rtol=1e-5)
+        assert torch.equal(o[half:half + B, :R], regs[None].expand(B, -1, -1))
+
+
+@pytest.mark.parametrize("apg", [False, True])
+def test_cfg_euler(L, apg):
+    B, T, C, R = 2, 11, 16, 4
+    y = torch.randn(B, T, C, generator=_g(1))
+    pred = torch.randn(2 * B, R + T, C, generator=_g(2))
+    dt = torch.tensor([0.1, 0.25, 0.05])
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)
+    pc, pn = pred[:B, R:], pred[B:, R:]
+    upd = pc - pn
+    if apg:
+        par, orth = O.apg_project(upd, pc)
+        upd = orth + par * 0.3
+    ref = y + dt[1] * (pc + upd * 2.0)
+    yd, pd = y.to(DEV), pred.to(DEV)
+    kw = dict(B=B, T=T, C_=C, pred_batch_stride=(R + T) * C, row_off=R)
+    buf = None
+    if apg:
+        buf = torch.zeros(2 * B, dtype=torch.float64, device=DEV)
+        L.apg_reduce(pd, buf, **kw)
+    L.cfg_euler(yd, pd, cfg_strength=2.0, dt=dt.to(DEV), step=step, apg=buf, keep=0.3, **kw)
+    L.step_advance(step)
+    torch.testing.assert_close(yd.cpu(), ref, atol=1e-5, rtol=1e-5)
+    assert int(step.item()) == 2

@@ -1,0 +1,134 @@
+"""GPU parity of the whole hot path through the drop-in E2TTS class (C ABI underneath):
+forward and 4-step CFG samples against tests/golden/ and the CPU oracle.
+Gate (BASELINE north_star): |delta mel| < 1e-3 in fp32 mode.  bf16 mode error is measured and
+bounded loosely (it is reported, not part of the 1e-3 claim)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import e2_cfm_oracle as O
+from conftest import make_model
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _kw(i):
+    return dict(text_embed=i["text"], context=i["ctx"], context_mask=i["ctx_mask"], frames_embed=i["roll"])
+
+
+@pytest.fixture(scope="module")
+def model_fp32(small):
+    return make_model(small["cfg"], small["P"], "fp32")
+
+
+@pytest.mark.parametrize("layout", ["interleaved", "half"])
+def test_forward_vs_golden(small, golden, layout):
+    cfg, i, g = small["cfg"], small["inp"], golden["forward_small"]
+    m = make_model(cfg, small["P"], "fp32", rope_layout=layout)
+    for drop, key in ((False, "pred_cond"), (True, "pred_null")):
+        p = m.transformer_with_pred_head(i["y0"], times=torch.tensor(0.37), text=i["text"], frames_embed=i["roll"],
+                                         context=i["ctx"], context_mask=i["ctx_mask"], drop_text_cond=drop, drop_text_prompt=drop)
+        err = np.abs(p.numpy() - g[f"{key}_{layout}"]).max()
+        assert err < 1e-4, (key, layout, err)
+
+
+def test_forward_layer_taps(small, golden, model_fp32):
+    """Layer-by-layer residual streams against the oracle taps: localises a wrong kernel."""
+    i, g, cfg = small["inp"], golden["forward_small"], small["cfg"]
+    m = model_fp32
+    m.transformer_with_pred_head(i["y0"], times=torch.tensor(0.37), text=i["text"], frames_embed=i["roll"],
+                                 context=i["ctx"], context_mask=i["ctx_mask"], drop_text_cond=False, drop_text_prompt=False)
+    p = m.engine().plan
+    np.testing.assert_allclose(p["t0"].cpu().numpy(), g["tap_text0"], atol=1e-5)
+    np.testing.assert_allclose(p["f0"].cpu().numpy(), g["tap_frames0"], atol=1e-5)
+
+
+def test_per_sample_times(small, model_fp32):
+    """transformer_with_pred_head accepts times of shape (b,) (x3:1997): per-sample modulation tables."""
+    cfg, P, i = small["cfg"], small["P"], small["inp"]
+    times = torch.tensor([0.1, 0.8])
+    got = model_fp32.transformer_with_pred_head(i["y0"], times=times, text=i["text"], frames_embed=i["roll"], context=i["ctx"],
+                                                context_mask=i["ctx_mask"], drop_text_cond=False, drop_text_prompt=False)
+    with torch.no_grad():
+        ref = O.transformer_with_pred_head(P, cfg, i["y0"], times, None, i["text"], i["roll"], i["ctx"], i["ctx_mask"],
+                                           drop_text_cond=False, drop_text_prompt=False)
+    assert float((got - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("case", ["y_full", "y_ragged", "y_dropprompt", "y_apg", "y_steps8_nosway"])
+def test_sample_vs_golden(small, golden, model_fp32, case):
+    i, g = small["inp"], golden["sample_small"]
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False, return_raw_output=True)
+    if case == "y_ragged":
+        kw.update(lens=torch.tensor([40, 29]), duration=torch.tensor([40, 29]))
+    if case == "y_dropprompt":
+        kw.update(video_drop_prompt=[False, True])
+    if case == "y_apg":
+        kw.update(remove_parallel_component=True)
+    if case == "y_steps8_nosway":
+        kw.update(steps=8, cfg_strength=3.0, sway_sampling=False)
+    y = model_fp32.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+    ref = g[case]
+    if case == "y_ragged":      # padded positions of the short clip are undefined in the reference too (x3:2256-2266)
+        assert np.abs(y.numpy()[0] - ref[0]).max() < TOL and np.abs(y.numpy()[1, :29] - ref[1, :29]).max() < TOL
+    else:
+        assert np.abs(y.numpy() - ref).max() < TOL, np.abs(y.numpy() - ref).max()
+
+
+def test_sample_half_layout_and_no_cross_rope(small, golden):
+    i, g = small["inp"], golden["sample_small"]
+    kw = dict(steps=4, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)
+    for name, mk in (("y_half_layout", dict(rope_layout="half")), ("y_norope_cross", dict(rope_cross=False))):
+        m = make_model(small["cfg"], small["P"], "fp32", **mk)
+        y = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+        assert np.abs(y.numpy() - g[name]).max() < TOL, name
+
+
+def test_graph_replay_equals_eager(small):
+    """The hipGraph-captured Euler step (device-side step counter) is bit-identical to eager launches,
+    and a second sample() call re-using the captured graph with new conditioning is too."""
+    i = small["inp"]
+    kw = dict(steps=5, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)
+    mg = make_model(small["cfg"], small["P"], "fp32", use_graph=True)
+    me = make_model(small["cfg"], small["P"], "fp32", use_graph=False)
+    a = mg.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+    b = me.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+    assert torch.equal(a, b)
+    i2 = dict(i, text=i["text"] * 0.5, ctx=i["ctx"] + 0.1)
+    a2 = mg.sample(torch.zeros(2, 40, 16), y0=i["y0"] * 0.9, **_kw(i2), **kw)
+    b2 = me.sample(torch.zeros(2, 40, 16), y0=i["y0"] * 0.9, **_kw(i2), **kw)
+    assert torch.equal(a2, b2) and not torch.equal(a, a2)
+
+
+def test_batch_independence(small, model_fp32):
+    """Clips are independent (what clip-level sharding relies on): sampling clip 1 alone == in a batch."""
+    i = small["inp"]
+    kw = dict(steps=4, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)
+    both = model_fp32.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+    one = {k: v[1:2] for k, v in i.items()}
+    solo = model_fp32.sample(torch.zeros(1, 40, 16), y0=one["y0"], **_kw(one), **kw)
+    assert float((both[1:2] - solo).abs().max()) < 1e-5
+
+
+def test_bf16_mode_error_is_bounded(small, golden):
+    """bf16 operands / fp32 accumulate + fp32 residual streams: measured, loosely bounded."""
+    i, g = small["inp"], golden["sample_small"]
+    m = make_model(small["cfg"], small["P"], "bf16")
+    y = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), steps=4, cfg_strength=2.0,
+                 remove_parallel_component=False, return_raw_output=True)
+    err = np.abs(y.numpy() - g["y_full"])
+    print(f"bf16 4-step sample: max |delta| = {err.max():.4f}, mean = {err.mean():.5f}")
+    assert err.max() < 0.25 and err.mean() < 0.02
+
+
+def test_missing_weights_and_unsupported_paths_raise(small):
+    import v2a_amd
+    m = make_model(small["cfg"], small["P"], "fp32")
+    i = small["inp"]
+    with pytest.raises(NotImplementedError):
+        m.sample(torch.zeros(2, 40, 16), lens=torch.tensor([20, 20]), duration=torch.tensor([40, 40]), y0=i["y0"], **_kw(i))
+    empty = v2a_amd.E2TTS(transformer=dict(dim=128, dim_text=192, dim_frames=64, depth=4, heads=2, frames_heads=1,
+                                           num_registers=4, max_seq_len=256), num_channels=16)
+    with pytest.raises(RuntimeError, match="never loaded"):
+        empty.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i))

@@ -127,6 +127,51 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+# ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
+_prof = None
+
+
+class KernelProfiler:
+    """Brackets every C-ABI launch with a pair of events recorded on the stream the kernel is
+    launched on (torch's current stream) and aggregates by kernel instantiation."""
+
+    def __init__(self):
+        self.recs = []
+
+    def launch(self, key, flops, nbytes, call):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        call()
+        e.record()
+        self.recs.append((key, flops, nbytes, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, nbytes, s, e in self.recs:
+            a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        return agg
+
+
+def set_profiler(p):
+    global _prof
+    _prof = p
+
+
+def _launch(key, flops, nbytes, call):
+    if _prof is None:
+        check(call())
+    else:
+        _prof.launch(key, flops, nbytes, lambda: check(call()))
+
+
+_EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
+
+
 # ------------------------------------------------------------------------------------------
 # thin typed wrappers (torch tensors are only carriers of device pointers here)
 # ------------------------------------------------------------------------------------------
@@ -157,24 +202,32 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.gate_step_stride = gate_step_stride
     g.gate_batch_stride = gate_batch_stride
     g.rows_per_batch = rows_per_batch
-    check(lib().v2a_gemm(C.byref(g), stream_ptr()))
+    K = sum(k for _, _, k in a_segs)
+    key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
+                                 _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
+    esz = 2 if compute == BF16 else 4
+    nbytes = M * K * (4 if g.a_dtype == F32 else 2) + N * K * esz + M * (N // 2 if epilogue == EPI_GEGLU else N) * out.element_size()
+    _launch(key, 2.0 * M * N * K, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
 
 
 def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch_stride=0, rows_per_batch=0,
             ldx=None, ldy=None):
-    check(lib().v2a_rmsnorm(x.data_ptr(), ldx or d, y.data_ptr(), ldy or d, dt_code(y.dtype), rows, d,
-                            gamma.data_ptr(), _p(step), gamma_step_stride, gamma_batch_stride, rows_per_batch,
-                            stream_ptr()))
+    _launch("rmsnorm<%s>" % ("f32" if y.dtype == torch.float32 else "bf16"), 0.0, rows * d * (4 + y.element_size()),
+            lambda: lib().v2a_rmsnorm(x.data_ptr(), ldx or d, y.data_ptr(), ldy or d, dt_code(y.dtype), rows, d,
+                                      gamma.data_ptr(), _p(step), gamma_step_stride, gamma_batch_stride, rows_per_batch,
+                                      stream_ptr()))
 
 
 def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None):
-    check(lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
-                                         B, N, d, ksize, _p(lens), stream_ptr()))
+    _launch("dwconv", 2.0 * B * N * d * ksize, B * N * d * 8,
+            lambda: lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                   B, N, d, ksize, _p(lens), stream_ptr()))
 
 
 def rope(qk, *, rows, row_stride, nheads, rows_per_batch, pos_offset, table, layout):
-    check(lib().v2a_rope_inplace(qk.data_ptr(), dt_code(qk.dtype), rows, row_stride, nheads, rows_per_batch,
-                                 pos_offset, table.data_ptr(), layout, stream_ptr()))
+    _launch("rope<%s>" % ("f32" if qk.dtype == torch.float32 else "bf16"), 0.0, rows * nheads * 64 * 2 * qk.element_size(),
+            lambda: lib().v2a_rope_inplace(qk.data_ptr(), dt_code(qk.dtype), rows, row_stride, nheads, rows_per_batch,
+                                           pos_offset, table.data_ptr(), layout, stream_ptr()))
 
 
 def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype):
@@ -186,7 +239,9 @@ def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=N
     a.B, a.H, a.Nq, a.Nk = B, H, Nq, Nk
     a.kv_len, a.q_len = _p(kv_len), _p(q_len)
     a.scale, a.softclamp, a.dtype = scale, softclamp, dtype
-    check(lib().v2a_attention(C.byref(a), stream_ptr()))
+    esz = 2 if dtype == BF16 else 4
+    _launch("attention<%s>" % ("bf16" if dtype == BF16 else "f32"), 4.0 * B * H * Nq * Nk * 64,
+            B * H * 64 * (2 * Nq + 2 * Nk) * esz, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
 
 
 def linear_small(a, wt, bias, add, out, *, M, K, T, out_batch_stride, row_off, d, dup=0):
@@ -208,8 +263,9 @@ def apg_reduce(pred, apg, *, B, T, C_, pred_batch_stride, row_off):
 
 
 def cfg_euler(y, pred, *, B, T, C_, pred_batch_stride, row_off, cfg_strength, dt, step=None, apg=None, keep=0.0):
-    check(lib().v2a_cfg_euler(y.data_ptr(), pred.data_ptr(), B, T, C_, pred_batch_stride, row_off,
-                              float(cfg_strength), dt.data_ptr(), _p(step), _p(apg), float(keep), stream_ptr()))
+    _launch("cfg_euler", 0.0, 16.0 * B * T * C_,
+            lambda: lib().v2a_cfg_euler(y.data_ptr(), pred.data_ptr(), B, T, C_, pred_batch_stride, row_off,
+                                        float(cfg_strength), dt.data_ptr(), _p(step), _p(apg), float(keep), stream_ptr()))
 
 
 def step_advance(step):

@@ -1,0 +1,464 @@
+"""Host side of the three-stream DiT (audio / CLIP-text / piano-frames) on MI355X.
+
+Mirrors `Transformer.forward` (x3:941-1143) + `transformer_with_pred_head` (x3:1993-2088)
+of the reference as a fixed launch sequence over the C-ABI kernels of include/v2a_cfm.h.
+`x3` = /root/reference/src/e2_tts_pytorch/e2_tts_crossatt3.py.
+
+What is restructured relative to the reference (results unchanged):
+  * cond + null CFG passes run as ONE batch of 2B sequences (x3:2099,2104 run them in turn);
+  * the FLAN-T5 output is an input (`context`), its per-layer cross-attention K/V (+RoPE on K)
+    are computed once per sample() instead of 2*(steps-1) times (x3:2057);
+  * cross-attention is skipped for the null half: context == 0 and bias-free to_k/to_v/to_out
+    make its output exactly 0 (x3:2058-2062);
+  * every AdaptiveRMSNorm / AdaLNZero modulation vector of every layer and every Euler grid
+    point is one fp32 GEMM at prepare() time (they depend on t only, x3:966-971);
+  * layer 0's text and frames blocks do not depend on x or t (cross-conditioning happens
+    after them, x3:1081-1104) and are hoisted out of the Euler loop;
+  * torch.cat of cross-condition / skip inputs is replaced by multi-segment GEMM operands.
+
+HBM layout: residual streams are fp32 (Bt, N, d) row-major with N = registers + frames;
+GEMM operands (norm outputs, q|k|v|gate, attention outputs, GEGLU hidden) are in the compute
+dtype (bf16, or fp32 in parity mode) and live in per-stream scratch buffers sized once per
+(B, T) plan, so a whole Euler step is allocation-free and hipGraph-capturable.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, asdict
+
+import torch
+
+from . import _lib as L
+
+NOTES = 51  # x3:70
+
+
+@dataclass
+class DiTConfig:
+    """predict.py:118-154 / x3:707-738 defaults."""
+    dim: int = 1024
+    dim_text: int = 1280
+    dim_frames: int = 512
+    depth: int = 12
+    heads: int = 16
+    dim_head: int = 64
+    frames_heads: int = 8           # x3:914
+    ff_mult: int = 4
+    kernel_size: int = 31
+    num_registers: int = 32
+    num_channels: int = 128
+    notes: int = NOTES
+    max_seq_len: int = 8192
+    dim_context: int | None = None
+
+    @property
+    def ctx_dim(self):
+        return self.dim if self.dim_context is None else self.dim_context
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Attn:
+    """Packed weights of one x-transformers Attention (A1, A5 of SURVEY 8c)."""
+
+    def __init__(self, sd, prefix, dim, heads, dh, cd, dev, cross=False):
+        inner = heads * dh
+        wq, wk, wv = sd[f"{prefix}.to_q.weight"], sd[f"{prefix}.to_k.weight"], sd[f"{prefix}.to_v.weight"]
+        wg, bg = sd[f"{prefix}.to_v_head_gate.weight"], sd[f"{prefix}.to_v_head_gate.bias"]
+        self.heads, self.inner = heads, inner
+        parts = [wq, wg] if cross else [wq, wk, wv, wg]
+        n = sum(p.shape[0] for p in parts)
+        self.n_pad = _ru(n, 16)
+        w = torch.zeros(self.n_pad, dim, dtype=torch.float32)
+        w[:n] = torch.cat([p.float() for p in parts], 0)
+        b = torch.zeros(self.n_pad, dtype=torch.float32)
+        self.gate_col = n - heads
+        b[self.gate_col:n] = bg.float()
+        self.w_in = w.to(dev, cd).contiguous()      # [q|k|v|gate] or [q|gate] rows
+        self.b_in = b.to(dev)
+        self.w_out = sd[f"{prefix}.to_out.weight"].to(dev, cd).contiguous()
+        self.wk, self.wv = (wk, wv) if cross else (None, None)
+
+
+class _FF:
+    """Packed GEGLU feed-forward (A8): W1 rows regrouped [16 value | 16 gate] per 16 outputs."""
+
+    def __init__(self, sd, prefix, dim, cd, dev):
+        w1, b1 = sd[f"{prefix}.ff.0.proj.weight"].float(), sd[f"{prefix}.ff.0.proj.bias"].float()
+        inner = w1.shape[0] // 2
+        assert inner % 16 == 0
+        self.inner = inner
+        wv, wg = w1[:inner].reshape(inner // 16, 1, 16, dim), w1[inner:].reshape(inner // 16, 1, 16, dim)
+        self.w1 = torch.cat([wv, wg], 1).reshape(2 * inner, dim).to(dev, cd).contiguous()
+        bv, bgt = b1[:inner].reshape(inner // 16, 1, 16), b1[inner:].reshape(inner // 16, 1, 16)
+        self.b1 = torch.cat([bv, bgt], 1).reshape(2 * inner).to(dev).contiguous()
+        self.w2 = sd[f"{prefix}.ff.2.weight"].to(dev, cd).contiguous()
+        self.b2 = sd[f"{prefix}.ff.2.bias"].float().to(dev).contiguous()
+
+
+class _Conv:
+    def __init__(self, sd, prefix, dev):
+        w = sd[f"{prefix}.dw_conv1d.0.weight"].float()          # (d, 1, k)
+        self.k = w.shape[-1]
+        self.wt = w[:, 0, :].t().contiguous().to(dev)            # [k][d]
+        self.b = sd[f"{prefix}.dw_conv1d.0.bias"].float().to(dev).contiguous()
+
+
+class PackedWeights:
+    """Reference state_dict (key layout of x3:824-933) -> device blobs."""
+
+    def __init__(self, cfg: DiTConfig, sd: dict, dev, cd: torch.dtype):
+        c = cfg
+        T = "transformer"
+        f32 = lambda k: sd[k].float().to(dev).contiguous()
+        self.pos_emb = f32(f"{T}.abs_pos_emb.weight")
+        self.regs = f32(f"{T}.registers")
+        self.text_regs = f32(f"{T}.text_registers")
+        self.frames_regs = f32(f"{T}.frames_registers")
+        self.fourier_w = f32(f"{T}.time_cond_mlp.0.weights")
+        self.time_wt = sd[f"{T}.time_cond_mlp.1.weight"].float().t().contiguous().to(dev)   # [d+1][d]
+        self.time_b = f32(f"{T}.time_cond_mlp.1.bias")
+        self.final_g = f32(f"{T}.final_norm.g")
+        self.pin_wt = sd["proj_in.weight"].float().t().contiguous().to(dev)                  # [C][d]
+        self.pin_b = f32("proj_in.bias")
+        self.pf_wt = sd["proj_frames.weight"].float().t().contiguous().to(dev)               # [51][df]
+        self.pf_b = f32("proj_frames.bias")
+        self.pred_w = sd["to_pred.weight"].to(dev, cd).contiguous()
+        self.pred_b = f32("to_pred.bias")
+        self.layers = []
+        ng, gw, gb, kw, vw = [], [], [], [], []
+        for i in range(c.depth):
+            P = f"{T}.layers.{i}"
+            ly = {}
+            if i >= c.depth // 2:
+                ly["skip"] = sd[f"{P}.0.0.weight"].to(dev, cd).contiguous()
+            ly["a_conv"] = _Conv(sd, f"{P}.0.1", dev)
+            ly["a_attn"] = _Attn(sd, f"{P}.0.3", c.dim, c.heads, c.dim_head, cd, dev)
+            ly["a_attn2"] = _Attn(sd, f"{P}.0.6", c.dim, c.heads, c.dim_head, cd, dev, cross=True)
+            ly["a_ff"] = _FF(sd, f"{P}.0.9", c.dim, cd, dev)
+            ng += [sd[f"{P}.0.2.to_gamma.weight"], sd[f"{P}.0.5.to_gamma.weight"], sd[f"{P}.0.8.to_gamma.weight"]]
+            gw += [sd[f"{P}.0.4.to_gamma.weight"], sd[f"{P}.0.7.to_gamma.weight"], sd[f"{P}.0.10.to_gamma.weight"]]
+            gb += [sd[f"{P}.0.4.to_gamma.bias"], sd[f"{P}.0.7.to_gamma.bias"], sd[f"{P}.0.10.to_gamma.bias"]]
+            kw.append(ly["a_attn2"].wk)
+            vw.append(ly["a_attn2"].wv)
+            ly["t_conv"] = _Conv(sd, f"{P}.1.0", dev)
+            ly["t_g1"] = f32(f"{P}.1.1.g")
+            ly["t_attn"] = _Attn(sd, f"{P}.1.2", c.dim_text, c.heads, c.dim_head, cd, dev)
+            ly["t_g2"] = f32(f"{P}.1.3.g")
+            ly["t_ff"] = _FF(sd, f"{P}.1.4", c.dim_text, cd, dev)
+            ly["x_tfa"] = sd[f"{P}.1.5.text_frames_to_audio.weight"].to(dev, cd).contiguous()
+            if i != c.depth - 1:
+                ly["x_at"] = sd[f"{P}.1.5.audio_to_text.weight"].to(dev, cd).contiguous()
+                ly["x_af"] = sd[f"{P}.1.5.audio_to_frames.weight"].to(dev, cd).contiguous()
+            ly["f_conv"] = _Conv(sd, f"{P}.2.0", dev)
+            ly["f_g1"] = f32(f"{P}.2.1.g")
+            ly["f_attn"] = _Attn(sd, f"{P}.2.2", c.dim_frames, c.frames_heads, c.dim_head, cd, dev)
+            ly["f_g2"] = f32(f"{P}.2.3.g")
+            ly["f_ff"] = _FF(sd, f"{P}.2.4", c.dim_frames, cd, dev)
+            self.layers.append(ly)
+        # modulation tables: rows ordered (layer, slot) with slot = attn / cross-attn / ff
+        self.norm_gamma_w = torch.cat([w.float() for w in ng], 0).to(dev).contiguous()       # (L*3*d, d) fp32
+        self.norm_gamma_b = torch.ones(self.norm_gamma_w.shape[0], device=dev)               # the "+1" of A10
+        self.gate_w = torch.cat([w.float() for w in gw], 0).to(dev).contiguous()
+        self.gate_b = torch.cat([b.float() for b in gb], 0).to(dev).contiguous()
+        # cross-attention K/V projections of every layer stacked: [K_0..K_{L-1} | V_0..V_{L-1}]
+        self.ctx_kv_w = torch.cat([w.float() for w in kw] + [w.float() for w in vw], 0).to(dev, cd).contiguous()
+        for ly in self.layers:
+            ly["a_attn2"].wk = ly["a_attn2"].wv = None
+
+
+class DiTEngine:
+    """One plan = fixed (Bt sequences, T frames, nc context tokens); all buffers preallocated."""
+
+    def __init__(self, cfg: DiTConfig, state_dict: dict, device="cuda", compute: str = "bf16",
+                 rope_layout: str = "interleaved", rope_cross: bool = True,
+                 zero_masked_queries: bool = True, softclamp: float = 50.0):
+        assert compute in ("bf16", "fp32")
+        assert cfg.dim_head == 64, "kernels are built for dim_head = 64 (x3:717)"
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.cd = torch.bfloat16 if compute == "bf16" else torch.float32
+        self.cdc = L.BF16 if compute == "bf16" else L.F32
+        self.rope_layout = {"interleaved": 0, "half": 1}[rope_layout]
+        self.rope_cross = rope_cross
+        self.zero_masked_queries = zero_masked_queries
+        self.softclamp = float(softclamp)
+        L.lib()  # fail loudly now if the HIP library is absent
+        self.W = PackedWeights(cfg, state_dict, self.dev, self.cd)
+        self.plan = None
+
+    # ------------------------------------------------------------------------------ planning
+    def setup(self, B: int, T: int, nc: int, S: int, cfg_mode: bool = True):
+        """B clips, T latent frames, nc context tokens, S time points (Euler evaluations)."""
+        key = (B, T, nc, S, cfg_mode)
+        if self.plan is not None and self.plan["key"] == key:
+            return self.plan
+        c, dev, cd = self.cfg, self.dev, self.cd
+        R = c.num_registers
+        N = T + R
+        Bt = 2 * B if cfg_mode else B
+        rows = Bt * N
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+        p = dict(key=key, B=B, Bt=Bt, T=T, N=N, nc=nc, S=S, rows=rows, cfg_mode=cfg_mode)
+        D, Dt, Df = c.dim, c.dim_text, c.dim_frames
+        p["xA"], p["xB"] = e(Bt, N, D), e(Bt, N, D)
+        p["skips"] = [e(Bt, N, D) for _ in range(c.depth // 2)]
+        p["tA"], p["tB"], p["t0"], p["tL0"] = e(Bt, N, Dt), e(Bt, N, Dt), e(Bt, N, Dt), e(Bt, N, Dt)
+        p["fA"], p["fB"], p["f0"], p["fL0"] = e(Bt, N, Df), e(Bt, N, Df), e(Bt, N, Df), e(Bt, N, Df)
+        W0 = self.W.layers[0]
+        for s, d, attn, ff in (("a", D, W0["a_attn"], W0["a_ff"]), ("t", Dt, W0["t_attn"], W0["t_ff"]),
+                               ("f", Df, W0["f_attn"], W0["f_ff"])):
+            p[f"hn_{s}"] = e(rows, d, dt=cd)
+            p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=cd)
+            p[f"ao_{s}"] = e(rows, attn.inner, dt=cd)
+            p[f"ffh_{s}"] = e(rows, ff.inner, dt=cd)
+        p["q2"] = e(B * N, W0["a_attn2"].n_pad, dt=cd)
+        inner = c.heads * c.dim_head
+        p["ctx_kv"] = e(B * nc, 2 * c.depth * inner, dt=cd)
+        p["ctx"] = e(B * nc, c.ctx_dim, dt=cd)
+        p["ctx_len"] = torch.full((B,), nc, dtype=torch.int32, device=dev)
+        p["pred"] = e(Bt, N, c.num_channels)
+        p["tc"] = e(S, D)
+        p["norm_tab"] = e(S, c.depth, 3, D)
+        p["gate_tab"] = e(S, c.depth, 3, D)
+        p["t_pts"] = e(S)
+        p["dt"] = e(S)
+        p["step"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        p["apg"] = torch.zeros(2 * B, dtype=torch.float64, device=dev)
+        p["seq_len"] = torch.full((Bt,), N, dtype=torch.int32, device=dev)
+        p["ragged"] = False
+        # rotary table (A6): cos/sin of pos * 10000^(-2i/64), computed like the oracle (CPU fp32)
+        inv = 1.0 / (10000 ** (torch.arange(0, c.dim_head, 2).float() / c.dim_head))
+        ang = torch.arange(N).float()[:, None] * inv[None, :]
+        p["rope"] = torch.stack((ang.cos(), ang.sin()), -1).contiguous().to(dev)            # (N, 32, 2)
+        p["per_sample_t"] = False
+        self.plan = p
+        return p
+
+    # --------------------------------------------------------------------------- primitives
+    def _norm_plain(self, x, hn, rows, d, g):
+        L.rmsnorm(x, hn, rows=rows, d=d, gamma=g)
+
+    def _norm_ada(self, x, hn, rows, d, layer, slot):
+        p = self.plan
+        tab = p["norm_tab"][0, layer, slot]
+        ss = p["norm_tab"].stride(0)
+        if p["per_sample_t"]:
+            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, gamma_batch_stride=ss, rows_per_batch=p["N"])
+        else:
+            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, step=p["step"], gamma_step_stride=ss, rows_per_batch=p["N"])
+
+    def _gate_kw(self, layer, slot):
+        p = self.plan
+        tab = p["gate_tab"][0, layer, slot]
+        ss = p["gate_tab"].stride(0)
+        if p["per_sample_t"]:
+            return dict(gate=tab, gate_batch_stride=ss, rows_per_batch=p["N"])
+        return dict(gate=tab, step=p["step"], gate_step_stride=ss, rows_per_batch=p["N"])
+
+    def _self_attn(self, A: _Attn, x, s, nseq, d, out_kw):
+        """x += epilogue(to_out(attend(rope(q), rope(k), v) * sigmoid(gate))), operand hn_s already normed."""
+        p = self.plan
+        N, rows = p["N"], nseq * p["N"]
+        hn, qkv, ao = p[f"hn_{s}"], p[f"qkv_{s}"], p[f"ao_{s}"]
+        L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad)
+        L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
+               table=p["rope"], layout=self.rope_layout)
+        es = qkv.element_size()
+        base = qkv.data_ptr()
+        lens = p["seq_len"] if p["ragged"] else None
+        L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
+                    strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, A.inner,
+                             N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.inner),
+                    B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens,
+                    q_len=lens if self.zero_masked_queries else None,
+                    scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.cdc)
+        L.gemm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, compute=self.cdc, resid=x, ldo=d, ldr=d, **out_kw)
+
+    def _ff(self, Fw: _FF, x, s, nseq, d, out_kw):
+        p = self.plan
+        rows = nseq * p["N"]
+        hn, ffh = p[f"hn_{s}"], p[f"ffh_{s}"]
+        L.gemm([(hn, d, d)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, compute=self.cdc, epilogue=L.EPI_GEGLU,
+               bias=Fw.b1, ldo=Fw.inner)
+        L.gemm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, compute=self.cdc, bias=Fw.b2, resid=x,
+               ldo=d, ldr=d, **out_kw)
+
+    def _side_block(self, ly, s, src, dst, nseq, d):
+        """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward."""
+        p = self.plan
+        N, rows = p["N"], nseq * p["N"]
+        lens = p["seq_len"] if p["ragged"] else None
+        cv = ly[f"{s}_conv"]
+        L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
+        self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g1"])
+        self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID))
+        self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g2"])
+        self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID))
+
+    # ------------------------------------------------------------------------------ prepare
+    def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
+                drop_text=None, drop_ctx=None, dt=None):
+        """Everything that is constant over the Euler loop.
+        text (B,T,Dt) f32 CLIP features, frames_roll (B,T,51) f32, context (B,nc,ctx) f32,
+        context_mask (B,nc) bool (prefix form), t_points (S,) f32 (host or device),
+        lens (B,) valid latent frames per clip or None, drop_text / drop_ctx: per-sequence
+        bool lists of length Bt / B (cfg_mode fills the null half itself)."""
+        p, c, W, dev = self.plan, self.cfg, self.W, self.dev
+        B, Bt, T, N, nc, S = p["B"], p["Bt"], p["T"], p["N"], p["nc"], p["S"]
+        R, D, Dt, Df = c.num_registers, c.dim, c.dim_text, c.dim_frames
+        assert text.shape == (B, T, Dt) and frames_roll.shape == (B, T, c.notes) and context.shape == (B, nc, c.ctx_dim)
+        # -- time conditioning + modulation tables for every grid point
+        p["t_pts"].copy_(t_points.to(dev, torch.float32))
+        if dt is not None:
+            p["dt"].copy_(dt.to(dev, torch.float32))
+        p["step"].zero_()
+        L.time_cond(p["t_pts"], W.fourier_w, W.time_wt, W.time_b, p["tc"], S=S, d=D)
+        nt = c.depth * 3 * D
+        L.gemm([(p["tc"], D, D)], W.norm_gamma_w, p["norm_tab"], M=S, N=nt, compute=L.F32, bias=W.norm_gamma_b, ldo=nt)
+        L.gemm([(p["tc"], D, D)], W.gate_w, p["gate_tab"], M=S, N=nt, compute=L.F32, epilogue=L.EPI_SIGMOID,
+               bias=W.gate_b, ldo=nt)
+        # -- sequence lengths (mask = lens_to_mask(duration) padded by R registers, x3:978-979, 2216)
+        if lens is not None and not bool((torch.as_tensor(lens) == T).all()):
+            sl = (torch.as_tensor(lens).to(torch.int32) + R).to(dev)
+            p["seq_len"].copy_(sl.repeat(Bt // B))
+            p["ragged"] = True
+        else:
+            p["seq_len"].fill_(N)
+            p["ragged"] = False
+        # -- step-invariant stream inputs: [registers ; features]
+        if drop_text is None:
+            drop_text = [False] * B + [True] * (Bt - B)
+        if drop_ctx is None:
+            drop_ctx = [False] * B
+        L.fill_registers(p["t0"], W.text_regs, B=Bt, R=R, d=Dt, out_batch_stride=N * Dt)
+        L.fill_registers(p["f0"], W.frames_regs, B=Bt, R=R, d=Df, out_batch_stride=N * Df)
+        tx = text.to(dev, torch.float32)
+        for s in range(Bt):                                   # device-memory plumbing, once per sample()
+            if drop_text[s]:
+                p["t0"][s, R:].zero_()                        # x3:2042-2044
+            else:
+                p["t0"][s, R:].copy_(tx[s % B])
+        fr = frames_roll.to(dev, torch.float32).contiguous()
+        L.linear_small(fr, W.pf_wt, W.pf_b, None, p["f0"], M=B * T, K=c.notes, T=T, out_batch_stride=N * Df,
+                       row_off=R, d=Df, dup=(B if Bt > B else 0))                           # x3:2069
+        # -- cross-attention K/V of every layer from the (possibly dropped) context
+        cx = context.to(dev, torch.float32).clone()
+        for b in range(B):
+            if drop_ctx[b]:
+                cx[b] = 0                                     # x3:2058-2062
+        p["ctx"].copy_(cx.reshape(B * nc, -1))
+        cm = context_mask.to(torch.bool).cpu()
+        cl = cm.sum(-1).to(torch.int32)
+        assert bool((cm == (torch.arange(nc)[None] < cl[:, None])).all()), "context_mask must be a prefix mask"
+        p["ctx_len"].copy_(cl)
+        inner = c.heads * c.dim_head
+        nkv = 2 * c.depth * inner
+        L.gemm([(p["ctx"], c.ctx_dim, c.ctx_dim)], W.ctx_kv_w, p["ctx_kv"], M=B * nc, N=nkv, compute=self.cdc, ldo=nkv)
+        if self.rope_cross:                                   # A7: keys take the LAST nc table rows
+            L.rope(p["ctx_kv"], rows=B * nc, row_stride=nkv, nheads=c.depth * c.heads, rows_per_batch=nc,
+                   pos_offset=N - nc, table=p["rope"], layout=self.rope_layout)
+        # -- hoisted layer-0 text / frames blocks
+        ly = W.layers[0]
+        self._side_block(ly, "t", p["t0"], p["tL0"], Bt, Dt)
+        self._side_block(ly, "f", p["f0"], p["fL0"], Bt, Df)
+
+    # ------------------------------------------------------------------------------ forward
+    def embed(self, y):
+        """x0 = [registers ; proj_in(y) + abs_pos_emb]  (x3:2027, 957-960, 975-976) into xA."""
+        p, c, W = self.plan, self.cfg, self.W
+        B, Bt, T, N, D = p["B"], p["Bt"], p["T"], p["N"], c.dim
+        L.fill_registers(p["xA"], W.regs, B=Bt, R=c.num_registers, d=D, out_batch_stride=N * D)
+        L.linear_small(y, W.pin_wt, W.pin_b, W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
+                       out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0))
+
+    def forward(self, n_ctx_seqs: int | None = None):
+        """Transformer.forward over the plan's Bt sequences starting from xA; result in plan['pred']."""
+        p, c, W = self.plan, self.cfg, self.W
+        B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
+        D, Dt, Df = c.dim, c.dim_text, c.dim_frames
+        nctx = B if n_ctx_seqs is None else n_ctx_seqs
+        lens = p["seq_len"] if p["ragged"] else None
+        half = c.depth // 2
+        inner = c.heads * c.dim_head
+        nkv = 2 * c.depth * inner
+        xc, xo = p["xA"], p["xB"]
+        tc_, fc_ = p["tL0"], p["fL0"]
+        tbuf, fbuf = [p["tA"], p["tB"]], [p["fA"], p["fB"]]
+        for i, ly in enumerate(W.layers):
+            if i > 0:
+                self._side_block(ly, "t", tc_, tbuf[1], Bt, Dt)
+                self._side_block(ly, "f", fc_, fbuf[1], Bt, Df)
+                tc_, fc_ = tbuf[1], fbuf[1]
+            # cross condition (x3:686-702): every update reads the PRE-update streams
+            xn = p["skips"][i] if i < half else xo
+            L.gemm([(xc, D, D), (tc_, Dt, Dt), (fc_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D, compute=self.cdc,
+                   epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D)
+            if i != c.depth - 1:
+                L.gemm([(xc, D, D), (tc_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt, compute=self.cdc,
+                       epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt)
+                L.gemm([(xc, D, D), (fc_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df, compute=self.cdc,
+                       epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df)
+                tc_, fc_ = tbuf[0], fbuf[0]
+            # U-Net skip (x3:1108-1117).  First half: the cross-condition output buffer IS the
+            # saved skip; xc is free again (all its readers are already queued) and takes the conv
+            # output.  Second half: skip_proj(cat(x, skip)) -> xc, conv -> xo, then swap.
+            if i < half:
+                src, dst = xn, xc
+            else:
+                L.gemm([(xn, D, D), (p["skips"][c.depth - 1 - i], D, D)], ly["skip"], xc, M=rows, N=D,
+                       compute=self.cdc, ldo=D)
+                src, dst = xc, xo
+            # audio stream (x3:1121-1137)
+            cv = ly["a_conv"]
+            L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
+            x = dst
+            self._norm_ada(x, p["hn_a"], rows, D, i, 0)
+            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0)))
+            if nctx > 0:
+                A2 = ly["a_attn2"]
+                r2 = nctx * N
+                self._norm_ada(x, p["hn_a"], r2, D, i, 1)
+                q2 = p["q2"]
+                L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad)
+                if self.rope_cross:
+                    L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
+                           table=p["rope"], layout=self.rope_layout)
+                es = q2.element_size()
+                kb = p["ctx_kv"].data_ptr() + i * inner * es
+                vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
+                L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, p["ao_a"].data_ptr(),
+                            strides=(A2.n_pad, nkv, nkv, A2.n_pad, inner,
+                                     N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * inner),
+                            B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
+                            q_len=lens if self.zero_masked_queries else None,
+                            scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.cdc)
+                L.gemm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, compute=self.cdc, resid=x, ldo=D, ldr=D,
+                       epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
+            self._norm_ada(x, p["hn_a"], rows, D, i, 2)
+            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2)))
+            if i >= half:
+                xc, xo = xo, xc
+        # final norm over all rows (registers are dropped by the consumer) + to_pred (x3:1141-1143, 2083)
+        L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g)
+        L.gemm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, compute=self.cdc, bias=W.pred_b,
+               ldo=c.num_channels)
+        return p["pred"]
+
+    def euler_step(self, y, cfg_strength: float, remove_parallel_component: bool = False, keep_parallel_frac: float = 0.0):
+        """One CFG + Euler evaluation, in place on y (B,T,C): the unit that is hipGraph-captured."""
+        p, c = self.plan, self.cfg
+        self.embed(y)
+        self.forward()
+        kw = dict(B=p["B"], T=p["T"], C_=c.num_channels, pred_batch_stride=p["N"] * c.num_channels, row_off=c.num_registers)
+        apg = None
+        if remove_parallel_component:
+            L.apg_reduce(p["pred"], p["apg"], **kw)
+            apg = p["apg"]
+        L.cfg_euler(y, p["pred"], cfg_strength=cfg_strength, dt=p["dt"], step=p["step"], apg=apg, keep=keep_parallel_frac, **kw)
+        L.step_advance(p["step"])

@@ -1,0 +1,433 @@
+"""Drop-in `E2TTS` for the sampling path: same constructor keywords, `sample()`,
+`transformer_with_pred_head()`, `cfg_transformer_with_pred_head()` and checkpoint key layout as
+the reference class (x3:1275-1318, 1993-2113, 2127-2305; `x3` =
+/root/reference/src/e2_tts_pytorch/e2_tts_crossatt3.py), running on the HIP kernels of
+include/v2a_cfm.h.  Callers: predict.py:266, app.py:267, src/inference_v2a.py:183,
+src/inference_v2p.py:183.
+
+Scope: the Euler/CFG loop over the DiT.  The encoders that feed it run
+once per clip and are out of scope, so their outputs are passed in through keyword-only
+extensions (`text_embed`, `context`, `context_mask`, `frames_embed`, `y0`) or produced by
+user-supplied callables (`video_encoder_fn`, `text_encoder_fn`, `frames_encoder_fn`).  The
+reference draws the initial noise on the device inside sample() (x3:2248); `y0` makes it
+injectable so results can be compared across devices.
+
+There is no fallback path: without libv2a_cfm.so (gfx950) construction raises.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from pathlib import Path
+from typing import Callable
+
+import torch
+
+from . import _lib as L
+from .dit import DiTConfig, DiTEngine, NOTES
+
+_IncompatibleKeys = namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+
+def lens_to_mask(t: torch.Tensor, length: int | None = None) -> torch.Tensor:
+    """x3:296-305."""
+    if length is None:
+        length = int(t.amax())
+    seq = torch.arange(length, device=t.device)
+    return seq[None, :] < t[:, None]
+
+
+def sway_grid(steps: int, sway_sampling: bool = True) -> torch.Tensor:
+    """x3:2250-2252, evaluated in fp32 on the host (same op order as the reference)."""
+    t = torch.linspace(0, 1, steps)
+    if sway_sampling:
+        t = t + -1.0 * (torch.cos(torch.pi / 2 * t) - 1 + t)
+    return t
+
+
+def expected_state_dict_shapes(cfg: DiTConfig) -> dict[str, tuple]:
+    """Key layout of the sampled path inside a reference checkpoint (nested ModuleList
+    indices of x3:824-933; SURVEY section 5 'Checkpoint / resume')."""
+    d, dt, df, k = cfg.dim, cfg.dim_text, cfg.dim_frames, cfg.kernel_size
+    inner, ih, fh = cfg.heads * cfg.dim_head, cfg.heads, cfg.frames_heads
+    s: dict[str, tuple] = {}
+
+    def attn(p, dim, heads, ctx=None):
+        inn = heads * cfg.dim_head
+        s[f"{p}.to_q.weight"] = (inn, dim)
+        s[f"{p}.to_k.weight"] = (inn, ctx or dim)
+        s[f"{p}.to_v.weight"] = (inn, ctx or dim)
+        s[f"{p}.to_v_head_gate.weight"] = (heads, dim)
+        s[f"{p}.to_v_head_gate.bias"] = (heads,)
+        s[f"{p}.to_out.weight"] = (dim, inn)
+
+    def ff(p, dim, mult):
+        s[f"{p}.ff.0.proj.weight"] = (2 * dim * mult, dim)
+        s[f"{p}.ff.0.proj.bias"] = (2 * dim * mult,)
+        s[f"{p}.ff.2.weight"] = (dim, dim * mult)
+        s[f"{p}.ff.2.bias"] = (dim,)
+
+    def conv(p, dim):
+        s[f"{p}.dw_conv1d.0.weight"] = (dim, 1, k)
+        s[f"{p}.dw_conv1d.0.bias"] = (dim,)
+
+    T = "transformer"
+    s[f"{T}.abs_pos_emb.weight"] = (cfg.max_seq_len, d)
+    s[f"{T}.registers"] = (cfg.num_registers, d)
+    s[f"{T}.text_registers"] = (cfg.num_registers, dt)
+    s[f"{T}.frames_registers"] = (cfg.num_registers, df)
+    s[f"{T}.time_cond_mlp.0.weights"] = (d // 2,)
+    s[f"{T}.time_cond_mlp.1.weight"] = (d, d + 1)
+    s[f"{T}.time_cond_mlp.1.bias"] = (d,)
+    for i in range(cfg.depth):
+        P = f"{T}.layers.{i}"
+        if i >= cfg.depth // 2:
+            s[f"{P}.0.0.weight"] = (d, 2 * d)
+        conv(f"{P}.0.1", d)
+        for j in (2, 5, 8):
+            s[f"{P}.0.{j}.to_gamma.weight"] = (d, d)
+        for j in (4, 7, 10):
+            s[f"{P}.0.{j}.to_gamma.weight"] = (d, d)
+            s[f"{P}.0.{j}.to_gamma.bias"] = (d,)
+        attn(f"{P}.0.3", d, ih)
+        attn(f"{P}.0.6", d, ih, cfg.ctx_dim)
+        ff(f"{P}.0.9", d, cfg.ff_mult)
+        conv(f"{P}.1.0", dt)
+        s[f"{P}.1.1.g"] = (dt,)
+        attn(f"{P}.1.2", dt, ih)
+        s[f"{P}.1.3.g"] = (dt,)
+        ff(f"{P}.1.4", dt, cfg.ff_mult)
+        s[f"{P}.1.5.text_frames_to_audio.weight"] = (d, d + dt + df)
+        if i != cfg.depth - 1:
+            s[f"{P}.1.5.audio_to_text.weight"] = (dt, d + dt)
+            s[f"{P}.1.5.audio_to_frames.weight"] = (df, d + df)
+        conv(f"{P}.2.0", df)
+        s[f"{P}.2.1.g"] = (df,)
+        attn(f"{P}.2.2", df, fh)
+        s[f"{P}.2.3.g"] = (df,)
+        ff(f"{P}.2.4", df, 4)
+    s[f"{T}.final_norm.g"] = (d,)
+    s["proj_in.weight"] = (d, cfg.num_channels)
+    s["proj_in.bias"] = (d,)
+    s["to_pred.weight"] = (cfg.num_channels, d)
+    s["to_pred.bias"] = (cfg.num_channels,)
+    s["proj_frames.weight"] = (df, cfg.notes)
+    s["proj_frames.bias"] = (df,)
+    return s
+
+
+class E2TTS:
+    def __init__(
+        self,
+        transformer: dict | None = None,
+        duration_predictor=None,
+        odeint_kwargs: dict = dict(method="euler"),
+        audiocond_drop_prob=0.30,
+        cond_drop_prob=0.20,
+        prompt_drop_prob=0.10,
+        num_channels=None,
+        mel_spec_module=None,
+        char_embed_kwargs: dict = dict(),
+        mel_spec_kwargs: dict = dict(),
+        frac_lengths_mask=(0.7, 1.0),
+        audiocond_snr=None,
+        concat_cond=False,
+        interpolated_text=False,
+        text_num_embeds=None,
+        tokenizer="char_utf8",
+        use_vocos=True,
+        pretrained_vocos_path="charactr/vocos-mel-24khz",
+        sampling_rate=None,
+        frame_size: int = 320,
+        velocity_consistency_weight=-1e-5,
+        if_cond_proj_in=True,
+        cond_proj_in_bias=True,
+        if_embed_text=True,
+        if_text_encoder2=True,
+        if_clip_encoder=False,
+        video_encoder="clip_vit",
+        *,
+        # ---- build-side extensions (keyword-only) ----
+        compute_dtype: str = "bf16",         # "bf16" | "fp32" (parity mode)
+        device="cuda",
+        rope_layout: str = "interleaved",
+        rope_cross: bool = True,
+        use_graph: bool = True,              # capture the Euler step in a hipGraph
+        video_encoder_fn: Callable | None = None,   # (video_paths, n) -> (b, n, dim_text)
+        text_encoder_fn: Callable | None = None,    # (prompts) -> ((b, nc, ctx) float, (b, nc) bool)
+        frames_encoder_fn: Callable | None = None,  # (frames, n) -> (b, n, NOTES)
+    ):
+        if not isinstance(transformer, dict):
+            raise TypeError("transformer must be the keyword dict of the reference (predict.py:120-134)")
+        if odeint_kwargs.get("method", "euler") != "euler":
+            raise NotImplementedError("only the fixed-grid Euler solver of the shipped config is built (x3:1282-1287)")
+        if concat_cond:
+            raise NotImplementedError("concat_cond=True is not used by any shipped caller")
+        tk = dict(transformer)
+        for flag in ("if_text_modules", "if_cross_attn", "if_audio_conv", "if_text_conv"):
+            if not tk.pop(flag, flag != "if_text_conv"):
+                raise NotImplementedError(f"{flag}=False: only the shipped configuration (all True, predict.py:126-129) is built")
+        tk.pop("cond_on_time", None)
+        if num_channels is None:
+            raise ValueError("num_channels is required (predict.py:152)")
+        self.cfg = DiTConfig(num_channels=num_channels, **tk)
+        self.dim, self.dim_text = self.cfg.dim, self.cfg.dim_text
+        self.num_channels = num_channels
+        self.sampling_rate = sampling_rate
+        self.frame_size = frame_size
+        self.audiocond_drop_prob, self.cond_drop_prob, self.prompt_drop_prob = audiocond_drop_prob, cond_drop_prob, prompt_drop_prob
+        self.duration_predictor = duration_predictor
+        self.mel_spec = mel_spec_module
+        self.vocos = None
+        self.video_encoder = video_encoder
+        self.training = False
+        self._device = torch.device(device)
+        self._compute = compute_dtype
+        self._rope = (rope_layout, rope_cross)
+        self._use_graph = use_graph
+        self.video_encoder_fn, self.text_encoder_fn, self.frames_encoder_fn = video_encoder_fn, text_encoder_fn, frames_encoder_fn
+        self._shapes = expected_state_dict_shapes(self.cfg)
+        self._sd: dict[str, torch.Tensor] = {}
+        self._engine: DiTEngine | None = None
+        self._graphs: dict = {}
+        L.lib()  # no library -> no sampler
+
+    # ---- nn.Module-like surface used by the callers (predict.py:156-170) -------------------
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, device):
+        self._device = torch.device(device)
+        self._engine = None
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def parameters(self):
+        return iter(self._sd.values())
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts a reference checkpoint's `model_state_dict` (predict.py:168, strict=False there):
+        keys of the sampled path are taken, encoder / vocoder / training-only keys are reported as
+        unexpected."""
+        missing, unexpected, new = [], [], {}
+        for k, shp in self._shapes.items():
+            if k in state_dict:
+                v = state_dict[k]
+                if tuple(v.shape) != tuple(shp):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(shp)}")
+                new[k] = v.detach().to("cpu", torch.float32).contiguous()
+            else:
+                missing.append(k)
+        unexpected = [k for k in state_dict if k not in self._shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict(strict=True): missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        self._sd.update(new)
+        self._engine = None
+        self._graphs = {}
+        return _IncompatibleKeys(missing, unexpected)
+
+    def engine(self) -> DiTEngine:
+        if self._engine is None:
+            absent = [k for k in self._shapes if k not in self._sd]
+            if absent:
+                raise RuntimeError(f"{len(absent)} parameters were never loaded (e.g. {absent[0]}): call load_state_dict first")
+            self._engine = DiTEngine(self.cfg, self._sd, self._device, compute=self._compute,
+                                     rope_layout=self._rope[0], rope_cross=self._rope[1])
+        return self._engine
+
+    # ---- conditioning helpers ---------------------------------------------------------------
+    def _get_context(self, prompt, context, context_mask, b):
+        if context is None:
+            if prompt is None:
+                raise ValueError("pass `prompt` (with text_encoder_fn) or precomputed `context`/`context_mask`")
+            if self.text_encoder_fn is None:
+                raise NotImplementedError("FLAN-T5 encoding is outside the accelerated path (SURVEY 8): supply "
+                                          "`context`/`context_mask` or construct with text_encoder_fn=")
+            context, context_mask = self.text_encoder_fn(list(prompt))     # encode_text x3:1648-1657
+        if context_mask is None:
+            context_mask = torch.ones(context.shape[:2], dtype=torch.bool)
+        assert context.shape[0] == b
+        return context, context_mask
+
+    # ---- reference API: one forward ----------------------------------------------------------
+    @torch.no_grad()
+    def transformer_with_pred_head(self, x, cond=None, times=None, mask=None, text=None, frames_embed=None,
+                                   prompt=None, video_drop_prompt=None, audio_drop_prompt=None,
+                                   drop_audio_cond: bool | None = None, drop_text_cond: bool | None = None,
+                                   drop_text_prompt: bool | None = None, return_drop_conditions=False,
+                                   *, context=None, context_mask=None):
+        """x3:1993-2088.  x (b,n,C); times (b,) or 0-dim; mask (b,n) bool prefix mask or None;
+        text (b,n,dim_text) float; frames_embed (b,n,NOTES).  Returns (b,n,C) on x.device."""
+        if cond is not None:
+            raise NotImplementedError("audio-conditioned infilling (cond != None) is not on the shipped sampling path "
+                                      "(if_cond_proj_in=False, predict.py:144; lens == duration, x3:2224-2226)")
+        if self.training:
+            raise NotImplementedError("training-time random condition dropping is out of scope")
+        b, n, _ = x.shape
+        dtc, dtp = bool(drop_text_cond), bool(drop_text_prompt)
+        eng = self.engine()
+        context, context_mask = self._get_context(prompt, context, context_mask, b)
+        times = torch.as_tensor(times, dtype=torch.float32)
+        if times.ndim == 0:
+            times = times.repeat(b)
+        eng.setup(b, n, context.shape[1], b, cfg_mode=False)
+        p = eng.plan
+        p["per_sample_t"] = True
+        lens = None if mask is None else _mask_to_lens(mask)
+        if frames_embed is None:
+            frames_embed = torch.zeros(b, n, self.cfg.notes)
+        drop_ctx = [dtp or bool(video_drop_prompt is not None and video_drop_prompt[i]) for i in range(b)]
+        eng.prepare(text, frames_embed, context, context_mask, times, lens=lens,
+                    drop_text=[dtc] * b, drop_ctx=drop_ctx)
+        eng.embed(x.to(self._device, torch.float32).contiguous())
+        pred = eng.forward(n_ctx_seqs=b)
+        out = pred[:, self.cfg.num_registers:, :].to(x.device).clone()
+        p["per_sample_t"] = False
+        if return_drop_conditions:
+            return out, [bool(drop_audio_cond)] * b, dtc, [dtp] * b
+        return out
+
+    @torch.no_grad()
+    def cfg_transformer_with_pred_head(self, *args, cfg_strength: float = 1.0, remove_parallel_component: bool = True,
+                                       keep_parallel_frac: float = 0.0, **kwargs):
+        """x3:2090-2113 (two forwards; sample() uses the batched in-engine form instead)."""
+        pred = self.transformer_with_pred_head(*args, drop_audio_cond=False, drop_text_cond=False, drop_text_prompt=False, **kwargs)
+        if cfg_strength < 1e-5:
+            return pred
+        null = self.transformer_with_pred_head(*args, drop_audio_cond=True, drop_text_cond=True, drop_text_prompt=True, **kwargs)
+        upd = pred - null
+        if remove_parallel_component:
+            shp = upd.shape
+            xd, yd = upd.reshape(shp[0], -1).double(), pred.reshape(shp[0], -1).double()
+            unit = torch.nn.functional.normalize(yd, dim=-1)
+            par = (xd * unit).sum(-1, keepdim=True) * unit
+            upd = ((xd - par) + par * keep_parallel_frac).reshape(shp).to(pred.dtype)
+        return pred + upd * cfg_strength
+
+    # ---- reference API: the sampler ------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, cond, *, text=None, lens=None, duration=None, steps=32, cfg_strength=1.0,
+               remove_parallel_component=True, sway_sampling=True, max_duration=4096, vocoder=None,
+               return_raw_output=None, save_to_filename=None, prompt=None, video_drop_prompt=None,
+               audio_drop_prompt=None, video_paths=None, frames=None, midis=None,
+               # build-side extensions
+               y0=None, text_embed=None, context=None, context_mask=None, frames_embed=None):
+        """x3:2127-2305.  `cond` (b, n, C) only fixes shape/device here (lens == duration on every
+        shipped call, so it is never used as audio conditioning: predict.py:261-263)."""
+        self.eval()
+        if cond.ndim == 2:
+            raise NotImplementedError("raw-wave `cond` needs mel_spec_module, which the shipped config does not set")
+        batch, cond_seq_len = cond.shape[:2]
+        out_device = cond.device
+        cfgm = self.cfg
+        # -- frames / piano roll (x3:2164-2176)
+        if frames_embed is None:
+            if frames is None:
+                frames_embed = torch.zeros(batch, cond_seq_len, cfgm.notes)
+            elif self.frames_encoder_fn is not None:
+                frames_embed = self.frames_encoder_fn(frames, cond_seq_len)
+            else:
+                raise NotImplementedError("Video2RollNet encode_frames is outside the accelerated path (SURVEY 8f N2): "
+                                          "pass frames_embed= or frames_encoder_fn=")
+        if frames_embed.shape[1] < cond_seq_len:
+            pad = torch.zeros(batch, cond_seq_len - frames_embed.shape[1], cfgm.notes, dtype=frames_embed.dtype, device=frames_embed.device)
+            frames_embed = torch.cat([frames_embed, pad], 1)
+        frames_embed = frames_embed[:, :cond_seq_len]
+        if lens is None:
+            lens = torch.full((batch,), cond_seq_len, dtype=torch.long)
+        lens = torch.as_tensor(lens).cpu().long()
+        # -- CLIP conditioning (x3:2183-2184)
+        if text_embed is None:
+            if video_paths is not None and self.video_encoder_fn is not None:
+                text_embed = self.video_encoder_fn(video_paths, cond_seq_len)
+            elif torch.is_tensor(text) and text.ndim == 3:
+                text_embed = text
+            else:
+                raise NotImplementedError("CLIP encode_video is outside the accelerated path (SURVEY 8f N3): pass "
+                                          "text_embed= (b, n, dim_text) or video_encoder_fn=")
+        # -- duration (x3:2196-2216)
+        if duration is None:
+            duration = lens.clone()
+        elif isinstance(duration, int):
+            duration = torch.full((batch,), duration, dtype=torch.long)
+        duration = torch.maximum(lens, torch.as_tensor(duration).cpu().long()).clamp(max=max_duration)
+        assert duration.shape[0] == batch
+        if not bool((lens == duration).all()):
+            raise NotImplementedError("lens != duration (audio-prompted continuation) is not on the shipped path")
+        n = int(duration.amax())
+        if n != cond_seq_len:
+            raise NotImplementedError("duration beyond cond length (padding of cond, x3:2212) is not on the shipped path")
+        context, context_mask = self._get_context(prompt, context, context_mask, batch)
+        drop_ctx = [bool(video_drop_prompt is not None and video_drop_prompt[i]) for i in range(batch)]
+        # -- grid (x3:2250-2252) and noise (x3:2248)
+        t = sway_grid(steps, sway_sampling)
+        S = steps - 1
+        if y0 is None:
+            y0 = torch.randn(batch, n, cfgm.num_channels, device=self._device)
+        eng = self.engine()
+        eng.setup(batch, n, context.shape[1], S, cfg_mode=True)
+        p = eng.plan
+        if "y" not in p:
+            p["y"] = torch.empty(batch, n, cfgm.num_channels, dtype=torch.float32, device=self._device)
+        eng.prepare(text_embed, frames_embed, context, context_mask, t[:-1], lens=duration,
+                    drop_ctx=drop_ctx, dt=t[1:] - t[:-1])
+        self._run_steps(eng, y0, S, float(cfg_strength), bool(remove_parallel_component))
+        out = p["y"].to(out_device).clone()
+        if return_raw_output:
+            return out
+        # -- waveform decode (x3:2270-2305), only if the caller attached a vocoder module
+        mask = lens_to_mask(duration)
+        if vocoder is not None:
+            return vocoder(out.transpose(1, 2))
+        if self.vocos is None:
+            return out
+        audio = [self.vocos.decode(mel[m].transpose(0, 1)[None]).squeeze(0) for mel, m in zip(out, mask)]
+        if save_to_filename is not None:
+            import torchaudio  # optional dependency of the caller's environment
+            path = Path(save_to_filename)
+            path.parents[0].mkdir(exist_ok=True, parents=True)
+            for ind, one in enumerate(audio):
+                name = path.name if len(audio) == 1 else f"{ind + 1}.{path.name}"
+                torchaudio.save(str(path.parents[0] / name), one.detach().cpu()[None], sample_rate=self.sampling_rate)
+        return audio
+
+    def _run_steps(self, eng: DiTEngine, y0, S, cfg_strength, apg):
+        """steps-1 Euler evaluations (A12 of SURVEY 8c).  cfg_strength < 1e-5 (x3:2101) still
+        runs the batched pass; the null half then has weight 0."""
+        p = eng.plan
+        y = p["y"]
+        y.copy_(y0.to(self._device, torch.float32))
+        p["step"].zero_()
+        if not self._use_graph:
+            for _ in range(S):
+                eng.euler_step(y, cfg_strength, apg)
+            return
+        key = (p["key"], cfg_strength, apg, p["ragged"])
+        g = self._graphs.get(key)
+        if g is None:
+            # warm-up on the real buffers (first-launch attribute calls must not happen under capture)
+            keep = y.clone()
+            eng.euler_step(y, cfg_strength, apg)
+            torch.cuda.synchronize()
+            y.copy_(keep)
+            p["step"].zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.euler_step(y, cfg_strength, apg)
+            self._graphs = {key: g}          # one plan is live at a time; drop graphs of older plans
+        for _ in range(S):
+            g.replay()
+
+
+def _mask_to_lens(mask: torch.Tensor) -> torch.Tensor:
+    mask = mask.to(torch.bool).cpu()
+    lens = mask.sum(-1)
+    if not bool((mask == lens_to_mask(lens, mask.shape[1])).all()):
+        raise NotImplementedError("only prefix masks (lens_to_mask form, x3:296-305) are supported")
+    return lens
