@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/v2a_cfm.h
+declares; argument validation answers without touching a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from v2a_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "v2a_cfm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(v2a_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(lib):
+    syms = _declared_symbols()
+    assert len(syms) >= 13, syms
+    L = lib.lib()
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/v2a_cfm.h but not exported"
+    assert sorted(lib.EXPORTS) == syms
+
+
+def test_abi_version_and_error_string(lib):
+    L = lib.lib()
+    assert L.v2a_abi_version() == 1
+    g = lib.GemmArgs()
+    g.nseg = 5
+    assert L.v2a_gemm(ctypes.byref(g), None) == -1                 # V2A_ERR_ARG, before any HIP call
+    assert b"nseg" in L.v2a_last_error()
+    assert L.v2a_rmsnorm(None, 0, None, 0, 0, 1, 64, None, None, 0, 0, 0, None) == -1
+    assert b"null" in L.v2a_last_error()
+    assert L.v2a_dwconv_silu_residual(1, 2, 3, 4, 1, 8, 64, 7, None, None) == -1
+    assert b"kernel_size" in L.v2a_last_error()
+
+
+def test_struct_layout_matches_header(lib):
+    """ctypes mirrors of v2a_gemm_args / v2a_attn_args: field order and sizes follow the header."""
+    src = open(os.path.join(ROOT, "include", "v2a_cfm.h")).read()
+    body = re.search(r"typedef struct v2a_gemm_args \{(.*?)\} v2a_gemm_args;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*$", part.strip())[0])
+    assert names == [f[0] for f in lib.GemmArgs._fields_]
+    assert ctypes.sizeof(lib.GemmArgs) % 8 == 0
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libv2a_cfm.so")
+    with pytest.raises(lib.V2AError, match="no CPU fallback"):
+        lib.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "video-to-audio-and-piano-rp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("CPU oracle", "").replace("like the oracle", ""), f

@@ -129,6 +129,6 @@ def test_missing_weights_and_unsupported_paths_raise(small):
     with pytest.raises(NotImplementedError):
         m.sample(torch.zeros(2, 40, 16), lens=torch.tensor([20, 20]), duration=torch.tensor([40, 40]), y0=i["y0"], **_kw(i))
     empty = v2a_amd.E2TTS(transformer=dict(dim=128, dim_text=192, dim_frames=64, depth=4, heads=2, frames_heads=1,
-                                           num_registers=4, max_seq_len=256), num_channels=16)
+                                           num_registers=4, max_seq_len=256, if_text_conv=True), num_channels=16)
     with pytest.raises(RuntimeError, match="never loaded"):
         empty.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i))
