@@ -32,6 +32,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+def log(*a):
+    print("[bench %.1fs]" % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity, cgroup quota and torch's own default,
+    capped at 16 (the GPU box's CPU share per GPU); os.cpu_count() reports the whole host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+_T0 = time.perf_counter()
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -76,8 +94,11 @@ def main():
                                            if_text_modules=True, if_cross_attn=True, if_audio_conv=True, if_text_conv=True),
                           num_channels=cfg.num_channels, sampling_rate=24000, if_cond_proj_in=False, tokenizer="phoneme_zh",
                           compute_dtype=args.dtype, device=dev, use_graph=not args.no_graph)
+    log("weights generated")
     model.load_state_dict(sd, strict=False)
     del sd
+    model.engine()
+    log("weights packed")
     y0, text, roll, ctx, cm = synthetic_conditioning(cfg, B, T, NC, seed=1000 + rank, piano=args.v2p, device=dev)
     cm = cm.cpu()
     cond = torch.empty(B, T, cfg.num_channels, device=dev)      # placeholder, as predict.py:261
@@ -90,8 +111,11 @@ def main():
                            sway_sampling=True, return_raw_output=True)
         return v2a_amd.gather_latents(out, n_clips, B)
 
-    for _ in range(args.warmup):
+    log("model ready: %s, B=%d/GPU, %d-point grid" % (args.dtype, B, cfm_steps))
+    for i in range(args.warmup):
         one_step()
+        torch.cuda.synchronize()
+        log("warmup %d done" % i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -107,6 +131,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     assert out.shape == (n_clips, T, cfg.num_channels) and bool(torch.isfinite(out).all())
+    log("timed %d steps: %.1f ms/step" % (args.steps, el / args.steps * 1e3))
 
     ms_per_step = el / args.steps * 1e3
     frames_per_s = n_clips * T / (el / args.steps)
@@ -130,6 +155,7 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_roofline:
             res["roofline"] = roofline_leg(model, L, y0, args)
+            log("roofline leg done")
         if not args.no_cpu_baseline:
             res.update(cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T))
     if rank == 0:
@@ -189,8 +215,9 @@ def cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T):
     imported here) on a bounded sample: B=1, `cpu-baseline-steps` grid points, all host
     cores, linearly extrapolated to the 31 evaluations of the headline (stated in `sample`)."""
     from oracle import e2_cfm_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log("cpu baseline: oracle on %d threads, %d-point grid" % (cores, args.cpu_baseline_steps))
     P = model.state_dict()
     ocfg = O.DiTConfig()
     s = args.cpu_baseline_steps

@@ -110,6 +110,174 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
   for (int c = 0; c < D; ++c) op[c] = from_f32<T>(o[c] * f);
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 MFMA flash kernel.  grid = (ceil(Nq/64), H, B), block = 256 = 4 waves x 16 queries.
+//
+// Swapped product S^T = K Q^T on v_mfma_f32_16x16x32_bf16: the accumulator has the QUERY on the
+// lane (col = lane & 15) and 4 keys per register group (row = 4*(lane>>4) + j), so
+//   * the softmax row max needs two wave shuffles (xor 16, xor 32), the row sum one at the end;
+//   * the fp32 P values, packed to bf16 in place, ARE the B operand of the next MFMA
+//     O^T = V^T P^T (k-slot (g, jj) <-> key 16*(2ks + jj/4) + 4g + jj%4; the V^T fragment is read
+//     in the same permuted key order), so P never touches LDS;
+//   * O^T has the query on the lane again, so the rescale factor alpha is a per-lane scalar.
+// K tiles sit in LDS row-major [key][64] with the 16-B chunk XOR-swizzled by (key & 7) (conflict-free
+// ds_read_b128 A fragments); V tiles are transposed on the way in to [d][68] (136-B rows: 8-B
+// aligned, conflict-free ds_read_b64 of 4 consecutive keys).  2-deep LDS ring, register prefetch.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tanh_fast(float x) {
+  // 1 - 2/(e^{2x}+1): saturates correctly at +-inf of the exponential
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+
+__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
+  constexpr int TK = 64, VLD = 68;
+  constexpr int K_ELEMS = TK * 64, V_ELEMS = 64 * VLD;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (K_ELEMS + V_ELEMS)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int query = q0 + lr;
+  const int kvn = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + b * p.qbs + h * 64;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(p.k) + b * p.kbs + h * 64;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(p.v) + b * p.vbs + h * 64;
+
+  bf16x8 qf[2];
+  {
+    const int qr = query < p.Nq ? query : p.Nq - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * p.qrs + 32 * kk + 8 * g);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const float sc = p.clamp > 0.f ? p.scale / p.clamp : p.scale;
+
+  // staging registers: K rows (tid>>3)+32i chunk tid&7; V key pair kp = lane&31, d-chunk = 2*wave + (lane>>5)
+  bf16x8 kreg[2], vreg[2];
+  const int kchunk = tid & 7, krow = tid >> 3;
+  const int kp = lane & 31, dch = wave * 2 + (lane >> 5);
+  auto load_tile = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = j0 + krow + 32 * i;
+      key = key < p.Nk ? key : p.Nk - 1;
+      kreg[i] = *reinterpret_cast<const bf16x8*>(Kg + (int64_t)key * p.krs + kchunk * 8);
+      int vk = j0 + 2 * kp + i;
+      vk = vk < p.Nk ? vk : p.Nk - 1;
+      vreg[i] = *reinterpret_cast<const bf16x8*>(Vg + (int64_t)vk * p.vrs + dch * 8);
+    }
+  };
+  auto store_tile = [&](bf16_t* base) {
+    bf16_t* ks = base;
+    bf16_t* vt = base + K_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = krow + 32 * i;
+      *reinterpret_cast<bf16x8*>(ks + row * 64 + ((kchunk ^ (row & 7)) << 3)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16x2 pr;
+      pr[0] = vreg[0][i];
+      pr[1] = vreg[1][i];
+      *reinterpret_cast<bf16x2*>(vt + (dch * 8 + i) * VLD + 2 * kp) = pr;
+    }
+  };
+
+  const int ntiles = (kvn + TK - 1) / TK;
+  load_tile(0);
+  store_tile(lds);
+  __syncthreads();
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const bf16_t* ks = lds + (jt & 1) * (K_ELEMS + V_ELEMS);
+    const bf16_t* vt = ks + K_ELEMS;
+    if (jt + 1 < ntiles) load_tile((jt + 1) * TK);
+    // ---- S^T = K Q^T : 4 key tiles x 2 k-steps
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = 16 * t + lr;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + row * 64 + (((kk * 4 + g) ^ (row & 7)) << 3));
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+      }
+    }
+    // ---- soft clamp, key mask, online softmax (query on the lane)
+    const int j0 = jt * TK;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = s[t][j] * sc;
+        if (p.clamp > 0.f) v = tanh_fast(v) * p.clamp;
+        if (j0 + 16 * t + 4 * g + j >= kvn) v = -INFINITY;
+        s[t][j] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(m, tmax);
+    const float alpha = __expf(m - mn);
+    m = mn;
+    l *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] *= alpha;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = __expf(s[t][j] - mn);
+        l += pv;
+        pf[t >> 1][(t & 1) * 4 + j] = (bf16_t)pv;
+      }
+    // ---- O^T += V^T P^T : 4 d tiles x 2 k-steps of 32 keys (permuted key order, see header)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16_t* vrow = vt + (16 * dt + lr) * VLD + 4 * g;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + 32 * ks2);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32 * ks2 + 16);
+        bf16x8 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = lo[j];
+          vf[4 + j] = hi[j];
+        }
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks2], o[dt], 0, 0, 0);
+      }
+    }
+    if (jt + 1 < ntiles) store_tile(lds + ((jt + 1) & 1) * (K_ELEMS + V_ELEMS));
+    __syncthreads();
+  }
+  // ---- epilogue: row sum across the 4 key groups, gate, query mask, 8-byte stores
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (query >= p.Nq) return;
+  const int qn = p.q_len ? min(p.q_len[b], p.Nq) : p.Nq;
+  float gt = 1.f;
+  if (p.gate) gt = sigmoid_f((float)reinterpret_cast<const bf16_t*>(p.gate)[b * p.gbs + (int64_t)query * p.grs + h]);
+  const float f = (query < qn && l > 0.f) ? gt / l : 0.f;
+  bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + b * p.obs + (int64_t)query * p.ors + h * 64 + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    bf16x4 ov;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ov[j] = (bf16_t)(o[dt][j] * f);
+    *reinterpret_cast<bf16x4*>(op + 16 * dt) = ov;
+  }
+}
+
 }  // namespace
 
 extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
@@ -126,9 +294,18 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   p.scale = a->scale; p.clamp = a->softclamp;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((a->Nq + 63) / 64, a->H, a->B), block(64);
-  if (a->dtype == V2A_F32)
+  if (a->dtype == V2A_F32) {
     hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((attn_rowlane_kernel<bf16_t>), grid, block, 0, s, p);
+  } else {
+    // MFMA path needs 16-byte aligned head slices for its vector loads and 8-byte aligned output rows
+    const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) == 0 && ((uintptr_t)a->out & 7) == 0 &&
+                         a->q_row_stride % 8 == 0 && a->k_row_stride % 8 == 0 && a->v_row_stride % 8 == 0 &&
+                         a->q_batch_stride % 8 == 0 && a->k_batch_stride % 8 == 0 && a->v_batch_stride % 8 == 0 &&
+                         a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
+    if (aligned)
+      hipLaunchKernelGGL(attn_mfma_kernel, dim3((a->Nq + 63) / 64, a->H, a->B), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((attn_rowlane_kernel<bf16_t>), grid, block, 0, s, p);
+  }
   return v2a_check_launch("v2a_attention");
 }
