@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="print a per-GEMM-shape timing table to stderr")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="grid points of the bounded CPU sample")
     args = ap.parse_args()
 
@@ -186,6 +187,20 @@ def roofline_leg(model, L, y0, args):
     finally:
         L.set_profiler(None)
     agg = prof.summary()
+    if args.shapes:       # per-shape GEMM table on stderr (tuning aid)
+        prof2 = L.KernelProfiler(shapes=True)
+        L.set_profiler(prof2)
+        try:
+            for _ in range(reps):
+                p["step"].zero_()
+                eng.euler_step(y, args.cfg_strength, False)
+        finally:
+            L.set_profiler(None)
+        a2 = prof2.summary()
+        tot2 = sum(a["ms"] for a in a2.values())
+        for k, a in sorted(a2.items(), key=lambda kv: -kv[1]["ms"]):
+            extra = ("%7.1f TF/s" % (a["flops"] / (a["ms"] * 1e-3) / 1e12)) if a["flops"] > 0 and k.startswith("gemm") else ("%7.1f GB/s" % (a["bytes"] / (a["ms"] * 1e-3) / 1e9))
+            log("%-58s n/eval=%3d avg=%7.2f us share=%5.1f%% %s" % (k, a["launches"] // reps, a["ms"] / a["launches"] * 1e3, 100 * a["ms"] / tot2, extra))
     y.copy_(keep)
     p["step"].zero_()
     table, tot_ms = {}, sum(a["ms"] for a in agg.values())

@@ -76,6 +76,8 @@ typedef struct v2a_gemm_args {
   void* out;             /* [M][N] (GEGLU: [M][N/2])                                    */
   int64_t ldo;
   int32_t out_dtype;     /* V2A_F32 | V2A_BF16 (RESID/GATE_RESID/SIGMOID: f32 only)     */
+  void* out_bf16;        /* optional bf16 shadow copy of an f32 output (operand of a later GEMM), or NULL */
+  int64_t ld_out_bf16;
   const float* resid;    /* [M][ldr] f32; may alias out                                 */
   int64_t ldr;
   const float* gate;     /* step vector of length N (GATE_RESID)                        */
@@ -185,6 +187,9 @@ int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C,
                   int64_t pred_batch_stride, int32_t row_off, float cfg_strength,
                   const float* dt, const int32_t* step, const double* apg,
                   float keep_parallel_frac, v2a_stream_t stream);
+/* y[i] = bf16(x[i]), n % 4 == 0: bf16 operand copy of an fp32 stream that no GEMM epilogue produced
+ * (the embed output x3:2027 feeding the first cross-condition GEMM) */
+int v2a_cast_bf16(const float* x, void* y, int64_t n, v2a_stream_t stream);
 /* step[0] += 1 (own launch: every block of the step has read step[0] before it runs) */
 int v2a_step_advance(int32_t* step, v2a_stream_t stream);
 

@@ -24,7 +24,18 @@ for s in "$@"; do
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 900 python bench.py --steps 3 --warmup 1 ;;
     bench_nocpu) run bench_nocpu 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
+    bench_shapes) run bench_shapes 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --shapes ;;
     bench8) run bench8 600 python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline ;;
+    tiles) for t in auto 0 1 2 3; do
+             if [ $t = auto ]; then unset V2A_GEMM_TILE; else export V2A_GEMM_TILE=$t; fi
+             TAILN=0 run tiles_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --shapes
+             echo "--- tile cfg $t"; grep -E "timed|gemm<" gpurun_out/tiles_$t.log | sed -E 's/\[bench [0-9.]+s\] //' | sort | head -40
+           done; unset V2A_GEMM_TILE ;;
+    dbg) for t in 0 1 2 4 6 7; do
+             export V2A_GEMM_DBG=$t
+             TAILN=0 run dbg_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --shapes
+             echo "--- dbg $t"; grep -E "timed|gemm<" gpurun_out/dbg_$t.log | sed -E 's/\[bench [0-9.]+s\] //' | sort | head -40
+           done; unset V2A_GEMM_DBG ;;
     prof) rm -rf gpurun_out/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline ;;
     *) echo "unknown step $s" ;;
   esac

@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("compute_dtype", C.c_int32), ("epilogue", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_dtype", C.c_int32),
+        ("out_bf16", C.c_void_p), ("ld_out_bf16", C.c_int64),
         ("resid", C.c_void_p), ("ldr", C.c_int64),
         ("gate", C.c_void_p), ("step", C.c_void_p),
         ("gate_step_stride", C.c_int64), ("gate_batch_stride", C.c_int64), ("rows_per_batch", C.c_int32),
@@ -56,7 +57,7 @@ class AttnArgs(C.Structure):
 EXPORTS = [
     "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
-    "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance",
+    "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
 ]
 
 
@@ -89,6 +90,7 @@ def _declare(lib):
     lib.v2a_apg_reduce.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp]
     lib.v2a_cfg_euler.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, f32, vp]
     lib.v2a_step_advance.argtypes = [vp, vp]
+    lib.v2a_cast_bf16.argtypes = [vp, vp, i64, vp]
     for name in EXPORTS:
         if name not in ("v2a_abi_version", "v2a_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -135,8 +137,9 @@ class KernelProfiler:
     """Brackets every C-ABI launch with a pair of events recorded on the stream the kernel is
     launched on (torch's current stream) and aggregates by kernel instantiation."""
 
-    def __init__(self):
+    def __init__(self, shapes: bool = False):
         self.recs = []
+        self.shapes = shapes      # key GEMM launches by MxNxK as well
 
     def launch(self, key, flops, nbytes, call):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -177,7 +180,8 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 # ------------------------------------------------------------------------------------------
 
 def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
-         step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None):
+         step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
+         out_bf16=None, ld_out_bf16=None):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
     g = GemmArgs()
     for i, (t, lda, k) in enumerate(a_segs):
@@ -195,6 +199,8 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.out = out.data_ptr()
     g.ldo = ldo if ldo is not None else out.stride(-2)
     g.out_dtype = dt_code(out.dtype)
+    g.out_bf16 = _p(out_bf16)
+    g.ld_out_bf16 = (ld_out_bf16 if ld_out_bf16 is not None else g.ldo) if out_bf16 is not None else 0
     g.resid = _p(resid)
     g.ldr = (ldr if ldr is not None else (resid.stride(-2) if resid is not None else 0))
     g.gate = _p(gate)
@@ -207,6 +213,8 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
     esz = 2 if compute == BF16 else 4
     nbytes = M * K * (4 if g.a_dtype == F32 else 2) + N * K * esz + M * (N // 2 if epilogue == EPI_GEGLU else N) * out.element_size()
+    if _prof is not None and _prof.shapes:
+        key += " %dx%dx%d" % (M, N, K)
     _launch(key, 2.0 * M * N * K, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
 
 
@@ -270,3 +278,7 @@ def cfg_euler(y, pred, *, B, T, C_, pred_batch_stride, row_off, cfg_strength, dt
 
 def step_advance(step):
     check(lib().v2a_step_advance(step.data_ptr(), stream_ptr()))
+
+
+def cast_bf16(x, y):
+    _launch("cast_bf16", 0.0, x.numel() * 6, lambda: lib().v2a_cast_bf16(x.data_ptr(), y.data_ptr(), x.numel(), stream_ptr()))

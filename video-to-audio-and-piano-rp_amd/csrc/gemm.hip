@@ -9,6 +9,7 @@
 // Block = 256 threads = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) in 16x16 MFMA tiles.
 // Register-staged global->LDS with a 2-deep LDS ring and one barrier per K tile.
 #include "v2a_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -23,12 +24,16 @@ struct GemmParams {
   int32_t M, N, K;
   void* out;
   int64_t ldo;
+  bf16_t* out2;      // optional bf16 shadow of an fp32 output (operand of a later GEMM)
+  int64_t ldo2;
   const float* resid;
   int64_t ldr;
   const float* gate;
   const int32_t* step;
   int64_t gss, gbs;
   int32_t rpb;
+  int32_t vec_epi;  // all epilogue pointers / strides allow 16-byte row pieces
+  int32_t dbg;   // tuning aid (env V2A_GEMM_DBG): 1 = skip epilogue stores, 2 = skip DMA issue, 4 = skip MFMA
 };
 
 template <typename T> struct TileCfg;
@@ -106,6 +111,148 @@ template <int ROWS> struct StageF32 {
 template <typename T, bool A_F32, int ROWS> struct StageSel;
 template <bool A_F32, int ROWS> struct StageSel<bf16_t, A_F32, ROWS> { using type = StageBf16<ROWS, A_F32>; };
 template <bool A_F32, int ROWS> struct StageSel<float, A_F32, ROWS> { using type = StageF32<ROWS>; };
+
+// ---- shared epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + j ------------------
+template <int EPI, typename OutT, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                              int lr, int lq) {
+  OutT* out = reinterpret_cast<OutT*>(p.out);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int m = m0 + wm * WM + i * 16 + lq * 4 + jj;
+      if (m >= p.M) continue;
+      const float* gvec = nullptr;
+      if constexpr (EPI == V2A_EPI_GATE_RESID) gvec = step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb);
+      if constexpr (EPI == V2A_EPI_GEGLU) {
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+          const int n = n0 + wn * WN + j * 16 + lr;  // packed row index of the value
+          if (n >= p.N) continue;
+          float v = acc[i][j][jj], g = acc[i][j + 1][jj];
+          if (p.bias) { v += p.bias[n]; g += p.bias[n + 16]; }
+          const int oc = ((n0 + wn * WN) >> 1) + (j >> 1) * 16 + lr;
+          const float ge = sizeof(OutT) == 2 ? gelu_fast_f(g) : gelu_erf_f(g);
+          out[(int64_t)m * p.ldo + oc] = from_f32<OutT>(v * ge);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WN + j * 16 + lr;
+          if (n >= p.N) continue;
+          float v = acc[i][j][jj];
+          if (p.bias) v += p.bias[n];
+          if constexpr (EPI == V2A_EPI_SIGMOID) v = sigmoid_f(v);
+          if constexpr (EPI == V2A_EPI_RESID) v += p.resid[(int64_t)m * p.ldr + n];
+          if constexpr (EPI == V2A_EPI_GATE_RESID) v = p.resid[(int64_t)m * p.ldr + n] + gvec[n] * v;
+          out[(int64_t)m * p.ldo + n] = from_f32<OutT>(v);
+          if constexpr (sizeof(OutT) == 4) {
+            if (p.out2) p.out2[(int64_t)m * p.ldo2 + n] = (bf16_t)v;
+          }
+        }
+      }
+    }
+  }
+}
+
+
+// ---- LDS-staged epilogue (DMA kernels) -----------------------------------------------------
+// The MFMA C layout gives a lane 4 ROWS of one column, so direct stores are 2-4 byte pieces.
+// Instead every wave parks its WM x WN fp32 tile in a private LDS region (the K-loop stages are
+// dead by then), and reads it back row-major 4 columns per lane: bias / GELU / gate / residual run
+// on float4s and every global access is a 16-byte (fp32) or 8-byte (bf16) piece of a contiguous row.
+template <int EPI, typename OutT, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[TM][TN], float* tile /* wave-private */,
+                                                  int m_base, int n_base, int lane) {
+  constexpr int LD = WN + 4;                   // 16-B aligned rows, <= 2-way write conflicts
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) tile[(i * 16 + lq * 4 + jj) * LD + j * 16 + lr] = acc[i][j][jj];
+  // same wave wrote and reads: LDS operations of one wave complete in order, no barrier needed
+  OutT* out = reinterpret_cast<OutT*>(p.out);
+  if constexpr (EPI == V2A_EPI_GEGLU) {
+    constexpr int OC = WN / 2;                 // output columns of this wave
+    constexpr int LPR = OC / 4;                // lanes per row
+    constexpr int RPI = 64 / LPR;              // rows per pass
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int lc = (c4 >> 4) * 32 + (c4 & 15); // LDS column of the value; gate is 16 further
+    const int n = n_base + lc;                 // packed W row of the value
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.N) {
+      bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+      bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
+    }
+#pragma unroll
+    for (int r = r0; r < WM; r += RPI) {
+      const int m = m_base + r;
+      if (m >= p.M || n >= p.N) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
+      OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
+      if constexpr (sizeof(OutT) == 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[e] + bv[e]) * gelu_fast_f(g[e] + bg[e]));
+        *reinterpret_cast<bf16x4*>(dst) = o;
+      } else {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[e] + bv[e]) * gelu_erf_f(g[e] + bg[e]);
+        *reinterpret_cast<f32x4*>(dst) = o;
+      }
+    }
+  } else {
+    constexpr int LPR = WN / 4;
+    constexpr int RPI = 64 / LPR;
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int n = n_base + c4;
+    const bool full = n + 3 < p.N;             // N is a multiple of 4 for every vector-eligible call (checked on the host)
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && full) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int r = r0; r < WM; r += RPI) {
+      const int m = m_base + r;
+      if (m >= p.M || !full) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      if constexpr (EPI == V2A_EPI_SIGMOID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+      }
+      if constexpr (EPI == V2A_EPI_RESID) {
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += rs[e];
+      }
+      if constexpr (EPI == V2A_EPI_GATE_RESID) {
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+        const f32x4 gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
+      }
+      if constexpr (sizeof(OutT) == 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x4*>(out + (int64_t)m * p.ldo + n) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldo + n) = v;
+        if (p.out2) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x4*>(p.out2 + (int64_t)m * p.ldo2 + n) = o;
+        }
+      }
+    }
+  }
+}
 
 // ---- the kernel ---------------------------------------------------------------------------
 template <typename T, bool A_F32, int EPI, typename OutT, int BM, int BN>
@@ -214,41 +361,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + j -------------------
-  OutT* out = reinterpret_cast<OutT*>(p.out);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int m = m0 + wm * WM + i * 16 + lq * 4 + jj;
-      if (m >= p.M) continue;
-      const float* gvec = nullptr;
-      if constexpr (EPI == V2A_EPI_GATE_RESID) gvec = step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb);
-      if constexpr (EPI == V2A_EPI_GEGLU) {
-#pragma unroll
-        for (int j = 0; j < TN; j += 2) {
-          const int n = n0 + wn * WN + j * 16 + lr;  // packed row index of the value
-          if (n >= p.N) continue;
-          float v = acc[i][j][jj], g = acc[i][j + 1][jj];
-          if (p.bias) { v += p.bias[n]; g += p.bias[n + 16]; }
-          const int oc = ((n0 + wn * WN) >> 1) + (j >> 1) * 16 + lr;
-          out[(int64_t)m * p.ldo + oc] = from_f32<OutT>(v * gelu_erf_f(g));
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * WN + j * 16 + lr;
-          if (n >= p.N) continue;
-          float v = acc[i][j][jj];
-          if (p.bias) v += p.bias[n];
-          if constexpr (EPI == V2A_EPI_SIGMOID) v = sigmoid_f(v);
-          if constexpr (EPI == V2A_EPI_RESID) v += p.resid[(int64_t)m * p.ldr + n];
-          if constexpr (EPI == V2A_EPI_GATE_RESID) v = p.resid[(int64_t)m * p.ldr + n] + gvec[n] * v;
-          out[(int64_t)m * p.ldo + n] = from_f32<OutT>(v);
-        }
-      }
-    }
-  }
+  gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
 }
 
 template <typename T, bool A_F32, int EPI, typename OutT, int BM, int BN>
@@ -295,6 +408,162 @@ int dispatch_epi(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
                   a->out_dtype, a->compute_dtype);
 }
 
+
+// ---- v2: bf16 x bf16, LDS-DMA staging, 3-deep ring -------------------------------------------
+// Both tiles arrive by global_load_lds_dwordx4 (1 KiB = 8 rows x 128 B per wave-instruction, LDS
+// image linear per wave, XOR swizzle applied to the per-lane SOURCE chunk: rule 21 of the CDNA guide),
+// two K tiles stay in flight across the single raw s_barrier of each iteration (counted vmcnt),
+// and no VGPRs or ds_writes are spent on staging.
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParams p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int GA = BM / 8, GW = BN / 8;       // 8-row DMA groups of the A and W tiles
+  constexpr int LPW = (GA + GW) / NW;           // DMA instructions per wave per K tile
+  static_assert((GA + GW) % NW == 0, "DMA groups must divide evenly over the waves");
+  static_assert(EPI != V2A_EPI_GEGLU || (TN % 2 == 0), "GEGLU needs value/gate tile pairs");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // M-fastest order: the workgroups an XCD runs back to back share one W panel (the big, HBM-streamed
+  // operand: fetched into that XCD's L2 once) and sweep the M bands of the small, L2-resident A.
+  const int tn = bid / tiles_m, tm = bid % tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane source geometry: lane -> (row in 8-row group = lane >> 3, physical chunk = lane & 7);
+  // DMA group g (0 .. GA+GW-1) is handled by wave g % NW; groups < GA are A rows, the rest W rows.
+  const int srow = lane >> 3;
+  const int schunk = ((lane & 7) ^ srow) << 3;  // logical chunk (elements) fetched into physical slot lane & 7
+  int grow[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const int g = wave + i * NW;
+    if (g < GA) {
+      const int r = m0 + g * 8 + srow;
+      grow[i] = r < p.M ? r : p.M - 1;
+    } else {
+      const int r = n0 + (g - GA) * 8 + srow;
+      grow[i] = r < p.N ? r : p.N - 1;
+    }
+  }
+  const bf16_t* wbase = reinterpret_cast<const bf16_t*>(p.w);
+
+  auto issue = [&](int kt) {
+    const int k0 = kt * 64;
+    int sgi = 0, kbeg = 0;
+    if (p.nseg > 1 && k0 >= p.kend[0]) { sgi = 1; kbeg = p.kend[0]; }
+    if (p.nseg > 2 && k0 >= p.kend[1]) { sgi = 2; kbeg = p.kend[1]; }
+    const bf16_t* abase = reinterpret_cast<const bf16_t*>(p.a[sgi]);
+    const int64_t lda = p.lda[sgi];
+    char* st = smem_raw + (kt % 3) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      const int g = wave + i * NW;
+      const bf16_t* src = g < GA ? abase + (int64_t)grow[i] * lda + (k0 - kbeg) + schunk
+                                 : wbase + (int64_t)grow[i] * p.ldw + k0 + schunk;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
+    }
+  };
+
+  const int nk = p.K / 64;
+  const bool do_dma = !(p.dbg & 2);
+  if (do_dma) issue(0);
+  if (nk > 1 && do_dma) issue(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed for this wave once at most the younger tile's DMAs remain outstanding
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1)%3
+    if (kt + 2 < nk && do_dma) issue(kt + 2);
+    if (p.dbg & 4) continue;
+    const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + (kt % 3) * STAGE_BYTES);
+    const bf16_t* Ws = As + BM * 64;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WM + i * 16 + lr;
+        af[i] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WN + j * 16 + lr;
+        bf[j] = *reinterpret_cast<const bf16x8*>(Ws + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+  if (p.vec_epi) {
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the K-loop stages; all DMAs were retired above
+    static_assert(NW * WM * (WN + 4) * 4 <= 3 * STAGE_BYTES, "epilogue tiles must fit in the stage memory");
+    float* tile = reinterpret_cast<float*>(smem_raw) + wave * (WM * (WN + 4));
+    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane);
+  } else {
+    gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
+  }
+}
+
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN>
+int launch_dma(const GemmParams& p, hipStream_t s) {
+  constexpr size_t smem = 3 * (size_t)(BM + BN) * 128;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WGM * WGN), smem, s, p);
+  return v2a_check_launch("v2a_gemm(dma)");
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
+  const bool out_f32 = a->out_dtype == V2A_F32;
+  switch (a->epilogue) {
+    case V2A_EPI_STORE:
+      return out_f32 ? launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN>(p, s) : launch_dma<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN>(p, s);
+    case V2A_EPI_GEGLU:
+      if (!out_f32) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN>(p, s);
+      break;
+    case V2A_EPI_RESID:
+      if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN>(p, s);
+      break;
+    case V2A_EPI_GATE_RESID:
+      if (out_f32) return launch_dma<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN>(p, s);
+      break;
+  }
+  return v2a_fail(V2A_ERR_ARG, "v2a_gemm(dma): unsupported epilogue %d / out_dtype %d", a->epilogue, a->out_dtype);
+}
+
 }  // namespace
 
 extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
@@ -329,6 +598,9 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   p.K = K;
   p.out = a->out;
   p.ldo = a->ldo;
+  p.out2 = reinterpret_cast<bf16_t*>(a->out_bf16);
+  p.ldo2 = a->ld_out_bf16;
+  if (a->out_bf16) V2A_REQUIRE(a->out_dtype == V2A_F32 && a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: out_bf16 shadows an fp32 output only");
   p.resid = a->resid;
   p.ldr = a->ldr;
   p.gate = a->gate;
@@ -336,6 +608,19 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   p.gss = a->gate_step_stride;
   p.gbs = a->gate_batch_stride;
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
+  {
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const int osz = a->out_dtype == V2A_F32 ? 4 : 2;
+    const int ncols = a->epilogue == V2A_EPI_GEGLU ? a->N / 2 : a->N;
+    bool ok = a->N % 4 == 0 && ncols % 4 == 0 && ((uintptr_t)a->out % (4 * osz)) == 0 && (a->ldo * osz) % (4 * osz) == 0;
+    if (a->bias) ok = ok && al16(a->bias);
+    if (a->resid) ok = ok && al16(a->resid) && a->ldr % 4 == 0;
+    if (a->gate) ok = ok && al16(a->gate) && a->gate_step_stride % 4 == 0 && a->gate_batch_stride % 4 == 0;
+    if (a->out_bf16) ok = ok && ((uintptr_t)a->out_bf16 & 7) == 0 && a->ld_out_bf16 % 4 == 0;
+    p.vec_epi = ok ? 1 : 0;
+  }
+  static const int dbg = getenv("V2A_GEMM_DBG") ? atoi(getenv("V2A_GEMM_DBG")) : 0;
+  p.dbg = dbg;
   if (a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID)
     V2A_REQUIRE(a->resid != nullptr, "v2a_gemm: epilogue %d needs resid", a->epilogue);
   if (a->epilogue == V2A_EPI_GATE_RESID) V2A_REQUIRE(a->gate != nullptr, "v2a_gemm: GATE_RESID needs gate");
@@ -343,5 +628,19 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a->compute_dtype == V2A_F32) return dispatch_epi<float, false, 128, 128>(a, p, s);
   if (a->a_dtype == V2A_F32) return dispatch_epi<bf16_t, true, 128, 128>(a, p, s);
-  return dispatch_epi<bf16_t, false, 128, 128>(a, p, s);
+  if (a->epilogue == V2A_EPI_SIGMOID) return dispatch_epi<bf16_t, false, 128, 128>(a, p, s);
+  // bf16 x bf16: LDS-DMA kernel; tile shape by how many workgroups the problem yields (256 CUs)
+  auto ntiles = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
+  static const int force = getenv("V2A_GEMM_TILE") ? atoi(getenv("V2A_GEMM_TILE")) : -1;   // tuning aid
+  int cfg;
+  if (force >= 0) cfg = force;
+  else if (a->N >= 2048 && ntiles(128, 256) >= 96) cfg = 0;   // wide outputs (QKV, GEGLU): measured best at M ~ 1.5k
+  else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;   // large M (batched clips)
+  else cfg = 3;
+  switch (cfg) {
+    case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);   // 8 waves, 144 KB LDS, 1 workgroup/CU
+    case 1: return dispatch_dma<128, 128, 2, 2>(a, p, s);   // 4 waves,  96 KB
+    case 2: return dispatch_dma<128, 64, 2, 2>(a, p, s);    // 4 waves,  72 KB, 2 workgroups/CU
+    default: return dispatch_dma<64, 64, 2, 2>(a, p, s);    // 4 waves,  48 KB, 3 workgroups/CU
+  }
 }

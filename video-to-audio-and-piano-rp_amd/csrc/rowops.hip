@@ -311,6 +311,16 @@ __global__ __launch_bounds__(256) void apg_reduce_kernel(const float* __restrict
 
 __global__ void step_advance_kernel(int32_t* step) { step[0] += 1; }
 
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+  *reinterpret_cast<bf16x4*>(y + 4 * i) = o;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -425,4 +435,10 @@ extern "C" int v2a_step_advance(int32_t* step, v2a_stream_t stream) {
   V2A_REQUIRE(step, "v2a_step_advance: null pointer");
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
   return v2a_check_launch("v2a_step_advance");
+}
+
+extern "C" int v2a_cast_bf16(const float* x, void* y, int64_t n, v2a_stream_t stream) {
+  V2A_REQUIRE(x && y && n > 0 && n % 4 == 0, "v2a_cast_bf16: bad args (n %% 4 must be 0)");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n / 4);
+  return v2a_check_launch("v2a_cast_bf16");
 }

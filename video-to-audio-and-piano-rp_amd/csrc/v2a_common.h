@@ -50,6 +50,15 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_exp + one v_rcp instead of libm erff's
+// branchy polynomial; used where the result is rounded to bf16 anyway.
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erfz = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erfz, x));
+}
 
 // step vector address: base + step[0]*step_stride + batch*batch_stride
 __device__ __forceinline__ const float* step_vec(const float* base, const int32_t* step, int64_t step_stride,

@@ -177,8 +177,9 @@ class DiTEngine:
 
     def __init__(self, cfg: DiTConfig, state_dict: dict, device="cuda", compute: str = "bf16",
                  rope_layout: str = "interleaved", rope_cross: bool = True,
-                 zero_masked_queries: bool = True, softclamp: float = 50.0):
+                 zero_masked_queries: bool = True, softclamp: float = 50.0, multi_stream: bool = True):
         assert compute in ("bf16", "fp32")
+        self.multi_stream = multi_stream
         assert cfg.dim_head == 64, "kernels are built for dim_head = 64 (x3:717)"
         self.cfg = cfg
         self.dev = torch.device(device)
@@ -217,6 +218,14 @@ class DiTEngine:
             p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=cd)
             p[f"ao_{s}"] = e(rows, attn.inner, dt=cd)
             p[f"ffh_{s}"] = e(rows, ff.inner, dt=cd)
+        # bf16 shadows of the fp32 residual streams (written by the producing GEMM epilogues): the
+        # operands of the cross-condition / skip GEMMs, so those run on the LDS-DMA bf16 kernel too
+        p["shadow"] = {}
+        if cd == torch.bfloat16:
+            for name in ("xA", "xB", "tA", "tB", "tL0", "fA", "fB", "fL0"):
+                p["shadow"][p[name].data_ptr()] = torch.empty_like(p[name], dtype=cd)
+            for sk in p["skips"]:
+                p["shadow"][sk.data_ptr()] = torch.empty_like(sk, dtype=cd)
         p["q2"] = e(B * N, W0["a_attn2"].n_pad, dt=cd)
         inner = c.heads * c.dim_head
         p["ctx_kv"] = e(B * nc, 2 * c.depth * inner, dt=cd)
@@ -237,10 +246,22 @@ class DiTEngine:
         ang = torch.arange(N).float()[:, None] * inv[None, :]
         p["rope"] = torch.stack((ang.cos(), ang.sin()), -1).contiguous().to(dev)            # (N, 32, 2)
         p["per_sample_t"] = False
+        # side streams: text block l+1 and frames block l+1 run beside the audio block l (see forward())
+        if self.dev.type == "cuda" and self.multi_stream:
+            p["st"], p["sf"] = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
         self.plan = p
         return p
 
     # --------------------------------------------------------------------------- primitives
+    def _sh(self, buf):
+        """bf16 shadow of an fp32 stream buffer (None in fp32 mode)."""
+        return self.plan["shadow"].get(buf.data_ptr())
+
+    def _opnd(self, buf):
+        """GEMM A operand for a residual stream: its bf16 shadow, or the fp32 buffer itself in fp32 mode."""
+        s = self._sh(buf)
+        return buf if s is None else s
+
     def _norm_plain(self, x, hn, rows, d, g):
         L.rmsnorm(x, hn, rows=rows, d=d, gamma=g)
 
@@ -287,7 +308,7 @@ class DiTEngine:
         L.gemm([(hn, d, d)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, compute=self.cdc, epilogue=L.EPI_GEGLU,
                bias=Fw.b1, ldo=Fw.inner)
         L.gemm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, compute=self.cdc, bias=Fw.b2, resid=x,
-               ldo=d, ldr=d, **out_kw)
+               ldo=d, ldr=d, out_bf16=self._sh(x), **out_kw)
 
     def _side_block(self, ly, s, src, dst, nseq, d):
         """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward."""
@@ -376,9 +397,19 @@ class DiTEngine:
         L.fill_registers(p["xA"], W.regs, B=Bt, R=c.num_registers, d=D, out_batch_stride=N * D)
         L.linear_small(y, W.pin_wt, W.pin_b, W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
                        out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0))
+        if self._sh(p["xA"]) is not None:
+            L.cast_bf16(p["xA"], self._sh(p["xA"]))
 
     def forward(self, n_ctx_seqs: int | None = None):
-        """Transformer.forward over the plan's Bt sequences starting from xA; result in plan['pred']."""
+        """Transformer.forward over the plan's Bt sequences starting from xA; result in plan['pred'].
+
+        Dependency structure of one layer i (x3:1081-1137): the text block T_i and frames block F_i need only
+        their own stream; the cross-condition reads the PRE-update x, text, frames; the audio block A_i needs
+        the cross-conditioned x.  Hence T_{i+1} and F_{i+1} run beside A_i.  With side streams this is
+        expressed by events (captured as hipGraph edges); without them everything is issued in order on
+        the current stream.  Events per layer: side blocks done (eT,eF), main's cross GEMM done (eX: the
+        side streams may then overwrite the text/frames buffers it read), side cross GEMMs done (eXt,eXf:
+        main may then overwrite x / its bf16 shadow)."""
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
         D, Dt, Df = c.dim, c.dim_text, c.dim_frames
@@ -390,29 +421,77 @@ class DiTEngine:
         xc, xo = p["xA"], p["xB"]
         tc_, fc_ = p["tL0"], p["fL0"]
         tbuf, fbuf = [p["tA"], p["tB"]], [p["fA"], p["fB"]]
+
+        main = torch.cuda.current_stream() if self.dev.type == "cuda" else None
+        st, sf = (p.get("st"), p.get("sf")) if main is not None else (None, None)
+        multi = st is not None
+
+        class _On:                      # run a block of launches on a side stream (or inline)
+            def __init__(self, s):
+                self.s = s
+            def __enter__(self):
+                if multi:
+                    self.ctx = torch.cuda.stream(self.s)
+                    self.ctx.__enter__()
+            def __exit__(self, *a):
+                if multi:
+                    self.ctx.__exit__(*a)
+
+        def rec(stream):
+            if not multi:
+                return None
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
+        def wait(stream, *evs):
+            if multi:
+                for e in evs:
+                    if e is not None:
+                        stream.wait_event(e)
+
+        eA = rec(main)                  # x (embed output) is ready; also forks the side streams into the capture
+        eT = eF = None                  # layer 0's side blocks were hoisted into prepare()
         for i, ly in enumerate(W.layers):
-            if i > 0:
-                self._side_block(ly, "t", tc_, tbuf[1], Bt, Dt)
-                self._side_block(ly, "f", fc_, fbuf[1], Bt, Df)
-                tc_, fc_ = tbuf[1], fbuf[1]
-            # cross condition (x3:686-702): every update reads the PRE-update streams
+            last = i == c.depth - 1
+            # main: cross condition onto the audio stream (x3:686-702); reads x, text, frames of this layer
+            wait(main, eT, eF)
             xn = p["skips"][i] if i < half else xo
-            L.gemm([(xc, D, D), (tc_, Dt, Dt), (fc_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D, compute=self.cdc,
-                   epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D)
-            if i != c.depth - 1:
-                L.gemm([(xc, D, D), (tc_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt, compute=self.cdc,
-                       epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt)
-                L.gemm([(xc, D, D), (fc_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df, compute=self.cdc,
-                       epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df)
-                tc_, fc_ = tbuf[0], fbuf[0]
-            # U-Net skip (x3:1108-1117).  First half: the cross-condition output buffer IS the
-            # saved skip; xc is free again (all its readers are already queued) and takes the conv
-            # output.  Second half: skip_proj(cat(x, skip)) -> xc, conv -> xo, then swap.
+            ax, at_, af_ = self._opnd(xc), self._opnd(tc_), self._opnd(fc_)
+            L.gemm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D, compute=self.cdc,
+                   epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn))
+            eX = rec(main)
+            eXt = eXf = None
+            if not last:
+                nxt = W.layers[i + 1]
+                # side streams: own cross-condition GEMM, then the NEXT layer's block
+                with _On(st):
+                    wait(st, eA)                                   # x of this layer (eT is on this stream already)
+                    L.gemm([(ax, D, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt, compute=self.cdc,
+                           epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt)
+                    eXt = rec(st)
+                    wait(st, eX)                                   # main has read this layer's text buffer
+                    self._side_block(nxt, "t", tbuf[0], tbuf[1], Bt, Dt)
+                    eT = rec(st)
+                with _On(sf):
+                    wait(sf, eA)
+                    L.gemm([(ax, D, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df, compute=self.cdc,
+                           epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df)
+                    eXf = rec(sf)
+                    wait(sf, eX)
+                    self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df)
+                    eF = rec(sf)
+                tc_, fc_ = tbuf[1], fbuf[1]
+            # main may overwrite x (and its shadow) only after the side cross GEMMs have read it
+            wait(main, eXt, eXf)
+            # U-Net skip (x3:1108-1117).  First half: the cross-condition output buffer IS the saved skip;
+            # xc is free again and takes the conv output.  Second half: skip_proj(cat(x, skip)) -> xc,
+            # conv -> xo, then swap.
             if i < half:
                 src, dst = xn, xc
             else:
-                L.gemm([(xn, D, D), (p["skips"][c.depth - 1 - i], D, D)], ly["skip"], xc, M=rows, N=D,
-                       compute=self.cdc, ldo=D)
+                L.gemm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], xc,
+                       M=rows, N=D, compute=self.cdc, ldo=D)
                 src, dst = xc, xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
@@ -442,6 +521,7 @@ class DiTEngine:
                        epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
             self._norm_ada(x, p["hn_a"], rows, D, i, 2)
             self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2)))
+            eA = rec(main)
             if i >= half:
                 xc, xo = xo, xc
         # final norm over all rows (registers are dropped by the consumer) + to_pred (x3:1141-1143, 2083)
