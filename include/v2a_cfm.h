@@ -84,6 +84,11 @@ typedef struct v2a_gemm_args {
   const int32_t* step;
   int64_t gate_step_stride, gate_batch_stride;
   int32_t rows_per_batch;
+  /* optional fused rotary embedding (bf16 STORE epilogue only): columns [0, rope_cols) are 64-wide heads whose
+   * interleaved pairs (2i, 2i+1) are rotated by cs_table[rope_pos_offset + m % rows_per_batch][i] = (cos, sin);
+   * replaces a separate v2a_rope_inplace(layout 0) pass over the fused [q|k|v|gate] output */
+  const float* rope_table;
+  int32_t rope_cols, rope_pos_offset;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
@@ -157,7 +162,9 @@ int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);
  * ------------------------------------------------------------------------------------- */
 int v2a_linear_small(const float* a, int64_t M, int32_t K, const float* wt, const float* bias,
                      const float* add, int32_t T, float* out, int64_t out_batch_stride,
-                     int32_t row_off, int32_t d, int32_t dup_batch_offset, v2a_stream_t stream);
+                     int32_t row_off, int32_t d, int32_t dup_batch_offset,
+                     const float* regs /* NULL, or [row_off][d]: also writes rows [0,row_off) = regs */,
+                     void* out_bf16 /* NULL, or bf16 shadow with out's geometry */, v2a_stream_t stream);
 
 /* out[b, r, :] = regs[r, :] for r < R, b < B  (register tokens, x3:975-997) */
 int v2a_fill_registers(float* out, int64_t out_batch_stride, const float* regs, int32_t B,

@@ -321,15 +321,47 @@ def test_linear_small_scatter_and_registers(L):
     a = torch.randn(B * T, K, generator=_g(1))
     w, bias, add = torch.randn(d, K, generator=_g(2)), torch.randn(d, generator=_g(3)), torch.randn(T, d, generator=_g(4))
     regs = torch.randn(R, d, generator=_g(5))
+    ref = (torch.nn.functional.linear(a, w, bias).reshape(B, T, d) + add[None])
+    # (a) separate register fill, no shadow (proj_frames form)
     out = torch.zeros(2 * B, R + T, d, device=DEV)
     L.fill_registers(out, regs.to(DEV), B=2 * B, R=R, d=d, out_batch_stride=(R + T) * d)
     L.linear_small(a.to(DEV), w.t().contiguous().to(DEV), bias.to(DEV), add.to(DEV), out, M=B * T, K=K, T=T,
                    out_batch_stride=(R + T) * d, row_off=R, d=d, dup=B)
-    ref = (torch.nn.functional.linear(a, w, bias).reshape(B, T, d) + add[None])
-    o = out.cpu()
-    for half in (0, B):
-        torch.testing.assert_close(o[half:half + B, R:], ref, atol=2e-5, rtol=1e-5)
-        assert torch.equal(o[half:half + B, :R], regs[None].expand(B, -1, -1))
+    # (b) fused register rows + bf16 shadow (embed form)
+    out_b = torch.zeros(2 * B, R + T, d, device=DEV)
+    sh = torch.zeros(2 * B, R + T, d, dtype=torch.bfloat16, device=DEV)
+    L.linear_small(a.to(DEV), w.t().contiguous().to(DEV), bias.to(DEV), add.to(DEV), out_b, M=B * T, K=K, T=T,
+                   out_batch_stride=(R + T) * d, row_off=R, d=d, dup=B, regs=regs.to(DEV), out_bf16=sh)
+    for o in (out.cpu(), out_b.cpu()):
+        for half in (0, B):
+            torch.testing.assert_close(o[half:half + B, R:], ref, atol=2e-5, rtol=1e-5)
+            assert torch.equal(o[half:half + B, :R], regs[None].expand(B, -1, -1))
+    assert torch.equal(sh.cpu(), out_b.cpu().bfloat16())
+
+
+@pytest.mark.parametrize("N,rope_cols", [(3 * 128 + 16, 256), (128 + 16, 128)])
+def test_gemm_fused_rope(L, N, rope_cols):
+    """RoPE (interleaved, A6) fused in the bf16 STORE epilogue == GEMM then the stand-alone rope kernel."""
+    rows_per_batch, Bt, K = 44, 2, 128
+    M = Bt * rows_per_batch
+    a = torch.randn(M, K, generator=_g(1)).bfloat16()
+    w = (torch.randn(N, K, generator=_g(2)) / math.sqrt(K)).bfloat16()
+    bias = torch.zeros(N)
+    bias[-16:] = torch.randn(16, generator=_g(3))
+    tab = _rope_table(rows_per_batch + 3).to(DEV)
+    fused = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm([(a.to(DEV), K, K)], w.to(DEV), fused, M=M, N=N, compute=L.BF16, bias=bias.to(DEV), rope_table=tab, rope_cols=rope_cols,
+           rope_pos_offset=3, rows_per_batch=rows_per_batch)
+    acc = a.float() @ w.float().t() + bias                              # fp32 accumulate of bf16 products
+    ref = acc.clone()
+    q = acc[:, :rope_cols].reshape(Bt, rows_per_batch, rope_cols // 64, 64).permute(0, 2, 1, 3)
+    fr = O.rotary_freqs(rows_per_batch + 3, 64, "interleaved")[3:]
+    ref[:, :rope_cols] = O.apply_rope(q, fr, "interleaved").permute(0, 2, 1, 3).reshape(M, rope_cols)
+    torch.testing.assert_close(fused.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    # and the un-rotated columns are exactly the plain GEMM's
+    plain = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm([(a.to(DEV), K, K)], w.to(DEV), plain, M=M, N=N, compute=L.BF16, bias=bias.to(DEV))
+    assert torch.equal(plain[:, rope_cols:], fused[:, rope_cols:])
 
 
 @pytest.mark.parametrize("apg", [False, True])

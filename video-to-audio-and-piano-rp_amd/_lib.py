@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("resid", C.c_void_p), ("ldr", C.c_int64),
         ("gate", C.c_void_p), ("step", C.c_void_p),
         ("gate_step_stride", C.c_int64), ("gate_batch_stride", C.c_int64), ("rows_per_batch", C.c_int32),
+        ("rope_table", C.c_void_p), ("rope_cols", C.c_int32), ("rope_pos_offset", C.c_int32),
     ]
 
 
@@ -84,7 +85,7 @@ def _declare(lib):
     lib.v2a_rmsnorm.argtypes = [vp, i64, vp, i64, i32, i64, i32, vp, vp, i64, i64, i32, vp]
     lib.v2a_dwconv_silu_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.v2a_rope_inplace.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, i32, vp]
-    lib.v2a_linear_small.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, vp]
+    lib.v2a_linear_small.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, vp]
     lib.v2a_fill_registers.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.v2a_time_cond.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp]
     lib.v2a_apg_reduce.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp]
@@ -181,7 +182,7 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 
 def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
-         out_bf16=None, ld_out_bf16=None):
+         out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
     g = GemmArgs()
     for i, (t, lda, k) in enumerate(a_segs):
@@ -208,6 +209,8 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.gate_step_stride = gate_step_stride
     g.gate_batch_stride = gate_batch_stride
     g.rows_per_batch = rows_per_batch
+    g.rope_table = _p(rope_table)
+    g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
@@ -252,9 +255,10 @@ def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=N
             B * H * 64 * (2 * Nq + 2 * Nk) * esz, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
 
 
-def linear_small(a, wt, bias, add, out, *, M, K, T, out_batch_stride, row_off, d, dup=0):
-    check(lib().v2a_linear_small(a.data_ptr(), M, K, wt.data_ptr(), _p(bias), _p(add), T, out.data_ptr(),
-                                 out_batch_stride, row_off, d, dup, stream_ptr()))
+def linear_small(a, wt, bias, add, out, *, M, K, T, out_batch_stride, row_off, d, dup=0, regs=None, out_bf16=None):
+    _launch("linear_small", 2.0 * M * K * d, M * (K + d) * 4,
+            lambda: lib().v2a_linear_small(a.data_ptr(), M, K, wt.data_ptr(), _p(bias), _p(add), T, out.data_ptr(),
+                                           out_batch_stride, row_off, d, dup, _p(regs), _p(out_bf16), stream_ptr()))
 
 
 def fill_registers(out, regs, *, B, R, d, out_batch_stride):

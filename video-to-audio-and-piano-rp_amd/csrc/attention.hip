@@ -156,11 +156,13 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
   float m = -INFINITY, l = 0.f;
   const float sc = p.clamp > 0.f ? p.scale / p.clamp : p.scale;
 
-  // staging registers: K rows (tid>>3)+32i chunk tid&7; V key pair kp = lane&31, d-chunk = 2*wave + (lane>>5)
-  bf16x8 kreg[2], vreg[2];
+  // staging registers: K rows (tid>>3)+32i chunk tid&7; V key pair kp = lane&31, d-chunk = 2*wave + (lane>>5).
+  // Two register sets: tile jt+2 is requested while tile jt is computed and tile jt+1 (requested one
+  // iteration earlier) is written to the other LDS buffer, so a global load has two iterations to land.
+  bf16x8 kregA[2], vregA[2], kregB[2], vregB[2];
   const int kchunk = tid & 7, krow = tid >> 3;
   const int kp = lane & 31, dch = wave * 2 + (lane >> 5);
-  auto load_tile = [&](int j0) {
+  auto load_tile = [&](int j0, bf16x8 (&kreg)[2], bf16x8 (&vreg)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key = j0 + krow + 32 * i;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
       vreg[i] = *reinterpret_cast<const bf16x8*>(Vg + (int64_t)vk * p.vrs + dch * 8);
     }
   };
-  auto store_tile = [&](bf16_t* base) {
+  auto store_tile = [&](bf16_t* base, const bf16x8 (&kreg)[2], const bf16x8 (&vreg)[2]) {
     bf16_t* ks = base;
     bf16_t* vt = base + K_ELEMS;
 #pragma unroll
@@ -189,13 +191,17 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
   };
 
   const int ntiles = (kvn + TK - 1) / TK;
-  load_tile(0);
-  store_tile(lds);
+  load_tile(0, kregA, vregA);
+  store_tile(lds, kregA, vregA);
+  if (ntiles > 1) load_tile(TK, kregA, vregA);          // tile 1 -> set A (odd tiles live in A, even tiles >= 2 in B)
   __syncthreads();
   for (int jt = 0; jt < ntiles; ++jt) {
     const bf16_t* ks = lds + (jt & 1) * (K_ELEMS + V_ELEMS);
     const bf16_t* vt = ks + K_ELEMS;
-    if (jt + 1 < ntiles) load_tile((jt + 1) * TK);
+    if (jt + 2 < ntiles) {
+      if (jt & 1) load_tile((jt + 2) * TK, kregA, vregA);
+      else load_tile((jt + 2) * TK, kregB, vregB);
+    }
     // ---- S^T = K Q^T : 4 key tiles x 2 k-steps
     f32x4 s[4];
 #pragma unroll
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
     }
     // ---- soft clamp, key mask, online softmax (query on the lane)
     const int j0 = jt * TK;
+    const bool partial = j0 + TK > kvn;
     float tmax = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
       for (int j = 0; j < 4; ++j) {
         float v = s[t][j] * sc;
         if (p.clamp > 0.f) v = tanh_fast(v) * p.clamp;
-        if (j0 + 16 * t + 4 * g + j >= kvn) v = -INFINITY;
+        if (partial && j0 + 16 * t + 4 * g + j >= kvn) v = -INFINITY;   // only the last tile can be partial
         s[t][j] = v;
         tmax = fmaxf(tmax, v);
       }
@@ -257,7 +264,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks2], o[dt], 0, 0, 0);
       }
     }
-    if (jt + 1 < ntiles) store_tile(lds + ((jt + 1) & 1) * (K_ELEMS + V_ELEMS));
+    if (jt + 1 < ntiles) {      // tile jt+1 was requested one iteration ago: odd tiles sit in set A, even in set B
+      bf16_t* nb = lds + ((jt + 1) & 1) * (K_ELEMS + V_ELEMS);
+      if ((jt + 1) & 1) store_tile(nb, kregA, vregA);
+      else store_tile(nb, kregB, vregB);
+    }
     __syncthreads();
   }
   // ---- epilogue: row sum across the 4 key groups, gate, query mask, 8-byte stores

@@ -32,6 +32,8 @@ struct GemmParams {
   const int32_t* step;
   int64_t gss, gbs;
   int32_t rpb;
+  const float* rope;     // cos/sin table [pos][32][2] or null: rotate interleaved pairs of columns < rope_cols (STORE epilogue)
+  int32_t rope_cols, rope_pos_off;
   int32_t vec_epi;  // all epilogue pointers / strides allow 16-byte row pieces
   int32_t dbg;   // tuning aid (env V2A_GEMM_DBG): 1 = skip epilogue stores, 2 = skip DMA issue, 4 = skip MFMA
 };
@@ -224,6 +226,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
       if constexpr (EPI == V2A_EPI_SIGMOID) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+      }
+      if constexpr (EPI == V2A_EPI_STORE) {
+        if (p.rope && n < p.rope_cols) {
+          // interleaved RoPE (A6): columns (n, n+1) and (n+2, n+3) are pairs (n & 63) / 2 and +1 of this head
+          const int pos = p.rope_pos_off + m % p.rpb;
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)pos * 32 + ((n & 63) >> 1)) * 2);
+          const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+          v[0] = a0 * cs[0] - b0 * cs[1];
+          v[1] = b0 * cs[0] + a0 * cs[1];
+          v[2] = a1 * cs[2] - b1 * cs[3];
+          v[3] = b1 * cs[2] + a1 * cs[3];
+        }
       }
       if constexpr (EPI == V2A_EPI_RESID) {
         const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
@@ -618,6 +632,14 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     if (a->gate) ok = ok && al16(a->gate) && a->gate_step_stride % 4 == 0 && a->gate_batch_stride % 4 == 0;
     if (a->out_bf16) ok = ok && ((uintptr_t)a->out_bf16 & 7) == 0 && a->ld_out_bf16 % 4 == 0;
     p.vec_epi = ok ? 1 : 0;
+  }
+  p.rope = a->rope_table;
+  p.rope_cols = a->rope_cols;
+  p.rope_pos_off = a->rope_pos_offset;
+  if (a->rope_table) {
+    V2A_REQUIRE(a->epilogue == V2A_EPI_STORE && a->compute_dtype == V2A_BF16 && a->a_dtype == V2A_BF16 && p.vec_epi &&
+                    a->rope_cols % 64 == 0 && a->rope_cols <= a->N && ((uintptr_t)a->rope_table & 15) == 0,
+                "v2a_gemm: fused RoPE needs the bf16 STORE epilogue with 16-byte aligned rows and rope_cols %% 64 == 0");
   }
   static const int dbg = getenv("V2A_GEMM_DBG") ? atoi(getenv("V2A_GEMM_DBG")) : 0;
   p.dbg = dbg;

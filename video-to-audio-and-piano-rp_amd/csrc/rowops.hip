@@ -170,43 +170,72 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qk, int64_t r
 }
 
 // ------------------------------------------------------------------------------------------
-// Small fp32 linear with row scatter (proj_in + abs_pos_emb + both CFG halves; proj_frames).
-// Block = 256 threads, ROWS input rows per block staged in LDS; thread n-strided outputs with
-// coalesced wt[k][n] reads.
+// Small fp32 linear with row scatter (proj_in + abs_pos_emb + register rows + both CFG halves + bf16
+// shadow; proj_frames).  grid = (row blocks of 8, batch); a thread owns 4 consecutive output columns
+// of 8 rows: per k one coalesced float4 of wt[k][:] and 8 LDS broadcasts feed 32 FMAs.
 // ------------------------------------------------------------------------------------------
 template <int ROWS>
-__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ a, int64_t M, int K,
-                                                           const float* __restrict__ wt, const float* __restrict__ bias,
-                                                           const float* __restrict__ add, int T, float* __restrict__ out,
-                                                           int64_t obs, int row_off, int d, int dup) {
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ a, int K, const float* __restrict__ wt,
+                                                           const float* __restrict__ bias, const float* __restrict__ add,
+                                                           int T, float* __restrict__ out, int64_t obs, int row_off, int d,
+                                                           int dup, const float* __restrict__ regs, bf16_t* __restrict__ out2) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* as = reinterpret_cast<float*>(smem_raw);  // [ROWS][K]
-  const int64_t m0 = (int64_t)blockIdx.x * ROWS;
+  const int b = blockIdx.y;
+  const int fill = regs ? row_off : 0;             // leading register rows written by this launch
+  const int rr0 = blockIdx.x * ROWS;               // row index within [0, fill + T)
   for (int i = threadIdx.x; i < ROWS * K; i += blockDim.x) {
-    const int64_t m = m0 + i / K;
-    as[i] = m < M ? a[m * K + (i % K)] : 0.f;
+    const int t = rr0 + i / K - fill;
+    as[i] = (t >= 0 && t < T) ? a[((int64_t)b * T + t) * K + (i % K)] : 0.f;
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < d; n += blockDim.x) {
-    float acc[ROWS];
+  for (int n = threadIdx.x * 4; n < d; n += blockDim.x * 4) {
+    f32x4 acc[ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+    for (int r = 0; r < ROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int k = 0; k < K; ++k) {
-      const float w = wt[(int64_t)k * d + n];
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wt + (int64_t)k * d + n);
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) acc[r] += as[r * K + k] * w;
+      for (int r = 0; r < ROWS; ++r) {
+        const float av = as[r * K + k];
+        acc[r][0] += av * w[0];
+        acc[r][1] += av * w[1];
+        acc[r][2] += av * w[2];
+        acc[r][3] += av * w[3];
+      }
     }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-      const int64_t m = m0 + r;
-      if (m >= M) break;
-      const int64_t b = m / T;
-      const int i = (int)(m % T);
-      float v = acc[r];
-      if (bias) v += bias[n];
-      if (add) v += add[(int64_t)i * d + n];
-      out[b * obs + (int64_t)(row_off + i) * d + n] = v;
-      if (dup > 0) out[(b + dup) * obs + (int64_t)(row_off + i) * d + n] = v;
+      const int rr = rr0 + r;
+      if (rr >= fill + T) break;
+      f32x4 v;
+      int orow;
+      if (rr < fill) {
+        v = *reinterpret_cast<const f32x4*>(regs + (int64_t)rr * d + n);
+        orow = rr;
+      } else {
+        const int t = rr - fill;
+        v = acc[r];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        if (add) {
+          const f32x4 ad = *reinterpret_cast<const f32x4*>(add + (int64_t)t * d + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += ad[e];
+        }
+        orow = row_off + t;
+      }
+      bf16x4 o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o2[e] = (bf16_t)v[e];
+      for (int h = 0; h < (dup > 0 ? 2 : 1); ++h) {
+        const int64_t off = (int64_t)(b + h * dup) * obs + (int64_t)orow * d + n;
+        *reinterpret_cast<f32x4*>(out + off) = v;
+        if (out2) *reinterpret_cast<bf16x4*>(out2 + off) = o2;
+      }
     }
   }
 }
@@ -379,13 +408,17 @@ extern "C" int v2a_rope_inplace(void* qk, int32_t dtype, int64_t rows, int64_t r
 
 extern "C" int v2a_linear_small(const float* a, int64_t M, int32_t K, const float* wt, const float* bias,
                                 const float* add, int32_t T, float* out, int64_t obs, int32_t row_off, int32_t d,
-                                int32_t dup, v2a_stream_t stream) {
+                                int32_t dup, const float* regs, void* out_bf16, v2a_stream_t stream) {
   V2A_REQUIRE(a && wt && out, "v2a_linear_small: null pointer");
-  V2A_REQUIRE(M > 0 && K > 0 && K <= 2048 && T > 0 && d > 0, "v2a_linear_small: M=%lld K=%d T=%d d=%d", (long long)M, K, T, d);
-  constexpr int ROWS = 4;
-  dim3 grid((unsigned)((M + ROWS - 1) / ROWS)), block(256);
-  hipLaunchKernelGGL((linear_small_kernel<ROWS>), grid, block, ROWS * K * sizeof(float), (hipStream_t)stream, a, M, K, wt,
-                     bias, add, T, out, obs, row_off, d, dup);
+  V2A_REQUIRE(M > 0 && K > 0 && K <= 2048 && T > 0 && d > 0 && d % 4 == 0 && M % T == 0, "v2a_linear_small: M=%lld K=%d T=%d d=%d",
+              (long long)M, K, T, d);
+  V2A_REQUIRE(obs % 4 == 0 && (((uintptr_t)out | (uintptr_t)wt | (uintptr_t)bias | (uintptr_t)add | (uintptr_t)regs) & 15) == 0 &&
+                  ((uintptr_t)out_bf16 & 7) == 0, "v2a_linear_small: 16-byte alignment");
+  constexpr int ROWS = 8;
+  const int rows = (regs ? row_off : 0) + T;
+  dim3 grid((unsigned)((rows + ROWS - 1) / ROWS), (unsigned)(M / T)), block(256);
+  hipLaunchKernelGGL((linear_small_kernel<ROWS>), grid, block, ROWS * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
+                     T, out, obs, row_off, d, dup, regs, (bf16_t*)out_bf16);
   return v2a_check_launch("v2a_linear_small");
 }
 

@@ -180,6 +180,8 @@ class DiTEngine:
                  zero_masked_queries: bool = True, softclamp: float = 50.0, multi_stream: bool = True):
         assert compute in ("bf16", "fp32")
         self.multi_stream = multi_stream
+        # RoPE rides in the QKV GEMM epilogue when pairs are lane-local (interleaved layout, bf16 DMA kernel)
+        self._fuse_rope = compute == "bf16" and rope_layout == "interleaved"
         assert cfg.dim_head == 64, "kernels are built for dim_head = 64 (x3:717)"
         self.cfg = cfg
         self.dev = torch.device(device)
@@ -287,9 +289,13 @@ class DiTEngine:
         p = self.plan
         N, rows = p["N"], nseq * p["N"]
         hn, qkv, ao = p[f"hn_{s}"], p[f"qkv_{s}"], p[f"ao_{s}"]
-        L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad)
-        L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
-               table=p["rope"], layout=self.rope_layout)
+        if self._fuse_rope:       # RoPE of the q and k heads inside the QKV GEMM epilogue
+            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad,
+                   rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N)
+        else:
+            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad)
+            L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
+                   table=p["rope"], layout=self.rope_layout)
         es = qkv.element_size()
         base = qkv.data_ptr()
         lens = p["seq_len"] if p["ragged"] else None
@@ -394,11 +400,9 @@ class DiTEngine:
         """x0 = [registers ; proj_in(y) + abs_pos_emb]  (x3:2027, 957-960, 975-976) into xA."""
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, T, N, D = p["B"], p["Bt"], p["T"], p["N"], c.dim
-        L.fill_registers(p["xA"], W.regs, B=Bt, R=c.num_registers, d=D, out_batch_stride=N * D)
         L.linear_small(y, W.pin_wt, W.pin_b, W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
-                       out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0))
-        if self._sh(p["xA"]) is not None:
-            L.cast_bf16(p["xA"], self._sh(p["xA"]))
+                       out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0),
+                       regs=W.regs, out_bf16=self._sh(p["xA"]))
 
     def forward(self, n_ctx_seqs: int | None = None):
         """Transformer.forward over the plan's Bt sequences starting from xA; result in plan['pred'].
@@ -504,10 +508,14 @@ class DiTEngine:
                 r2 = nctx * N
                 self._norm_ada(x, p["hn_a"], r2, D, i, 1)
                 q2 = p["q2"]
-                L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad)
-                if self.rope_cross:
-                    L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
-                           table=p["rope"], layout=self.rope_layout)
+                if self.rope_cross and self._fuse_rope:
+                    L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad,
+                           rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N)
+                else:
+                    L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad)
+                    if self.rope_cross:
+                        L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
+                               table=p["rope"], layout=self.rope_layout)
                 es = q2.element_size()
                 kb = p["ctx_kv"].data_ptr() + i * inner * es
                 vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
