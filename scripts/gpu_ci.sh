@@ -36,9 +36,13 @@ for s in "$@"; do
              TAILN=0 run dbg_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --shapes
              echo "--- dbg $t"; grep -E "timed|gemm<" gpurun_out/dbg_$t.log | sed -E 's/\[bench [0-9.]+s\] //' | sort | head -40
            done; unset V2A_GEMM_DBG ;;
-    pmc1) rm -rf gpurun_out/pmc1; run pmc1 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc1 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph ;;
-    pmc2) rm -rf gpurun_out/pmc2; run pmc2 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc2 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph ;;
-    pmc3) rm -rf gpurun_out/pmc3; run pmc3 900 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc3 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-graph ;;
+    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph"
+         i=0
+         for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
+           i=$((i+1)); rm -rf /tmp/pmc$i
+           run pmc$i 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc$i -- $B || true
+           python scripts/pmc_summary.py /tmp/pmc$i gpurun_out/pmc${i}_summary.csv
+         done ;;
     prof) rm -rf gpurun_out/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline ;;
     *) echo "unknown step $s" ;;
   esac

@@ -10,6 +10,7 @@
 // Register-staged global->LDS with a 2-deep LDS ring and one barrier per K tile.
 #include "v2a_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -467,9 +468,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 
   // per-lane source geometry: lane -> (row in 8-row group = lane >> 3, physical chunk = lane & 7);
   // DMA group g (0 .. GA+GW-1) is handled by wave g % NW; groups < GA are A rows, the rest W rows.
+  // Each slot keeps ONE 32-bit per-lane byte offset for the whole K loop; the K advance and the
+  // operand base are wave-uniform (SGPR), so an issue costs no vector address arithmetic.
   const int srow = lane >> 3;
   const int schunk = ((lane & 7) ^ srow) << 3;  // logical chunk (elements) fetched into physical slot lane & 7
   int grow[LPW];
+  uint32_t goff[LPW];
+  auto set_offsets = [&](int64_t lda) {
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      const int g = wave + i * NW;
+      goff[i] = (uint32_t)(((int64_t)grow[i] * (g < GA ? lda : p.ldw) + schunk) * 2);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
     const int g = wave + i * NW;
@@ -481,38 +492,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
       grow[i] = r < p.N ? r : p.N - 1;
     }
   }
-  const bf16_t* wbase = reinterpret_cast<const bf16_t*>(p.w);
+  int cur_seg = 0;
+  set_offsets(p.lda[0]);
+  const char* wbase = reinterpret_cast<const char*>(p.w);
 
-  auto issue = [&](int kt) {
+  auto issue = [&](int kt, int stage) {
     const int k0 = kt * 64;
     int sgi = 0, kbeg = 0;
     if (p.nseg > 1 && k0 >= p.kend[0]) { sgi = 1; kbeg = p.kend[0]; }
     if (p.nseg > 2 && k0 >= p.kend[1]) { sgi = 2; kbeg = p.kend[1]; }
-    const bf16_t* abase = reinterpret_cast<const bf16_t*>(p.a[sgi]);
-    const int64_t lda = p.lda[sgi];
-    char* st = smem_raw + (kt % 3) * STAGE_BYTES;
+    if (sgi != cur_seg) {            // at most twice per kernel: the next A segment has its own row stride
+      cur_seg = sgi;
+      set_offsets(p.lda[sgi]);
+    }
+    const char* ab = reinterpret_cast<const char*>(p.a[sgi]) + (int64_t)(k0 - kbeg) * 2;   // wave-uniform
+    const char* wb = wbase + (int64_t)k0 * 2;
+    char* st = smem_raw + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
       const int g = wave + i * NW;
-      const bf16_t* src = g < GA ? abase + (int64_t)grow[i] * lda + (k0 - kbeg) + schunk
-                                 : wbase + (int64_t)grow[i] * p.ldw + k0 + schunk;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      const char* base = g < GA ? ab : wb;                                                  // scalar select
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
                                        (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
     }
   };
 
   const int nk = p.K / 64;
   const bool do_dma = !(p.dbg & 2);
-  if (do_dma) issue(0);
-  if (nk > 1 && do_dma) issue(1);
-  for (int kt = 0; kt < nk; ++kt) {
+  if (do_dma) issue(0, 0);
+  if (nk > 1 && do_dma) issue(1, 1);
+  // one K tile; STAGE is a compile-time ring position so every LDS address is base + immediate
+  auto tile = [&](auto stage_c, int kt) {
+    constexpr int STAGE = decltype(stage_c)::value;
     // tile kt has landed for this wave once at most the younger tile's DMAs remain outstanding
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1)%3
-    if (kt + 2 < nk && do_dma) issue(kt + 2);
-    if (p.dbg & 4) continue;
-    const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + (kt % 3) * STAGE_BYTES);
+    if (kt + 2 < nk && do_dma) issue(kt + 2, (STAGE + 2) % 3);
+    if (p.dbg & 4) return;
+    const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
     const bf16_t* Ws = As + BM * 64;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -533,6 +551,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+  };
+  for (int kt = 0; kt < nk; kt += 3) {
+    tile(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) tile(std::integral_constant<int, 1>{}, kt + 1);
+    if (kt + 2 < nk) tile(std::integral_constant<int, 2>{}, kt + 2);
   }
   if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   if (p.vec_epi) {
