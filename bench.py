@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--v2p", action="store_true", help="configs[3]: non-zero piano roll, 64 steps")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="no side streams: kernels run one at a time (profiling aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="print a per-GEMM-shape timing table to stderr")
@@ -77,11 +78,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)             # rehearsal of N ranks on fewer devices (V2A_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    backend = os.environ.get("V2A_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import v2a_amd
     from v2a_amd import _lib as L
@@ -98,7 +105,7 @@ def main():
     log("weights generated")
     model.load_state_dict(sd, strict=False)
     del sd
-    model.engine()
+    model.engine().multi_stream = not args.single_stream
     log("weights packed")
     y0, text, roll, ctx, cm = synthetic_conditioning(cfg, B, T, NC, seed=1000 + rank, piano=args.v2p, device=dev)
     cm = cm.cpu()
@@ -128,7 +135,7 @@ def main():
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     assert out.shape == (n_clips, T, cfg.num_channels) and bool(torch.isfinite(out).all())
@@ -147,7 +154,7 @@ def main():
                                "evaluations (%d DiT forwards), T5 context %d tokens, %s"
                                % (3 if args.v2p else 1, B, T, cfm_steps, evals, 2 * evals, NC, "V2P roll" if args.v2p else "V2A zero roll"),
                    "clips_per_gpu": B, "global_clips": n_clips, "parallelism": "clip-sharded x%d, 1 all-gather" % world,
-                   "hipgraph": not args.no_graph},
+                   "hipgraph": not args.no_graph, "side_streams": not args.single_stream},
         "per_gpu_mel_frames_per_s": round(frames_per_s / world, 2),
         "clips_per_s": round(n_clips / (el / args.steps), 4),
         "ms_per_cfg_evaluation": round(ms_per_step / evals, 4),
@@ -174,6 +181,7 @@ def roofline_leg(model, L, y0, args):
     p = eng.plan
     y = p["y"]
     reps = 3
+    side = (p.pop("st", None), p.pop("sf", None))     # kernels one at a time: isolated launch durations
     prof = L.KernelProfiler()
     keep = y.clone()
     # warm: one untimed eager evaluation
@@ -203,6 +211,8 @@ def roofline_leg(model, L, y0, args):
             log("%-58s n/eval=%3d avg=%7.2f us share=%5.1f%% %s" % (k, a["launches"] // reps, a["ms"] / a["launches"] * 1e3, 100 * a["ms"] / tot2, extra))
     y.copy_(keep)
     p["step"].zero_()
+    if side[0] is not None:
+        p["st"], p["sf"] = side
     table, tot_ms = {}, sum(a["ms"] for a in agg.values())
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         row = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
@@ -219,10 +229,44 @@ def roofline_leg(model, L, y0, args):
     all_f = sum(a["flops"] for _, a in gem)
     all_ms = sum(a["ms"] for _, a in gem)
     return {"bound": "mfma", "kernel": dom_k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": None,
+            "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom_k),
             "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2), "launches_per_eval": dom["launches"] // reps,
             "all_gemm_tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(all_f / (all_ms * 1e-3) / 1e12 / peak, 4),
             "eager_eval_kernel_ms": round(tot_ms / reps, 3), "kernels": table}
+
+
+def pmc_traffic(kernel_key):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc{1,2}_summary.csv; FETCH_SIZE and WRITE_SIZE collected in separate passes, KB units,
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC collection cannot run inside
+    the timed bench, so this is the recorded figure for the same kernel instantiation, or None."""
+    import csv
+    epi = {"store": "0", "sigmoid": "1", "geglu": "2", "resid": "3", "gate_resid": "4"}
+    try:
+        parts = kernel_key[len("gemm<"):-1].split(",")
+        tag_e, tag_o = "Li%sE" % epi[parts[2]], ("DF16b" if parts[3] == "bf16" else "f")
+        def rows(fn):
+            return list(csv.DictReader(open(os.path.join(ROOT, "profiles", fn))))
+        def pick(rs):
+            # demangled "<E, out, ...>" or mangled "ILi<E>E<out>..." names of gemm_bf16_dma_kernel
+            best = None
+            for r in rs:
+                k = r["kernel"]
+                if "gemm_bf16_dma_kernel" not in k:
+                    continue
+                ok = k.startswith("gemm_bf16_dma_kernel<%s, %s" % (epi[parts[2]], "float" if tag_o == "f" else "__bf16")) or                      k.startswith("gemm_bf16_dma_kernel<%s%s" % (tag_e, tag_o))
+                if ok and (best is None or int(r["dispatches"]) > int(best["dispatches"])):
+                    best = r
+            return best
+        f, w = pick(rows("r01_pmc1_summary.csv")), pick(rows("r01_pmc2_summary.csv"))
+        if f is None or w is None:
+            return None
+        fetch = float(f["FETCH_SIZE"]) * 1024 * 2 / int(f["dispatches"])
+        write = float(w["WRITE_SIZE"]) * 1024 / int(w["dispatches"])
+        return {"bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
+                "source": "profiles/r01_pmc1_summary.csv + r01_pmc2_summary.csv (rocprofv3 --pmc, separate passes; FETCH_SIZE x2)"}
+    except Exception:
+        return None
 
 
 def cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T):

@@ -101,6 +101,22 @@ def test_graph_replay_equals_eager(small):
     assert torch.equal(a2, b2) and not torch.equal(a, a2)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_side_streams_do_not_change_results(small, mode):
+    """Text/frames blocks of layer l+1 beside the audio block of layer l (events / hipGraph edges) ==
+    everything in order on one stream, bit for bit; also graph replay == eager in bf16 (fused RoPE,
+    bf16 shadows, LDS-DMA GEMMs are all on this path)."""
+    import v2a_amd
+    i = small["inp"]
+    kw = dict(steps=4, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)
+    outs = []
+    for ms, graph in ((True, True), (False, False), (True, False)):
+        m = make_model(small["cfg"], small["P"], mode, use_graph=graph)
+        m._engine = v2a_amd.DiTEngine(m.cfg, m._sd, m.device, compute=mode, multi_stream=ms)
+        outs.append(m.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_batch_independence(small, model_fp32):
     """Clips are independent (what clip-level sharding relies on): sampling clip 1 alone == in a batch."""
     i = small["inp"]

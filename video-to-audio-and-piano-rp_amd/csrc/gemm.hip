@@ -677,9 +677,11 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   // bf16 x bf16: LDS-DMA kernel; tile shape by how many workgroups the problem yields (256 CUs)
   auto ntiles = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
   static const int force = getenv("V2A_GEMM_TILE") ? atoi(getenv("V2A_GEMM_TILE")) : -1;   // tuning aid
+  static const int small = getenv("V2A_GEMM_SMALL") ? atoi(getenv("V2A_GEMM_SMALL")) : -1;
   int cfg;
   if (force >= 0) cfg = force;
   else if (a->N >= 2048 && ntiles(128, 256) >= 96) cfg = 0;   // wide outputs (QKV, GEGLU): measured best at M ~ 1.5k
+  else if (small >= 0) cfg = small;                                     // tuning aid: V2A_GEMM_SMALL
   else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;   // large M (batched clips)
   else cfg = 3;
   switch (cfg) {

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // that use it; the k tap weights (float4 each, [k][d] layout -> coalesced) stay in registers.
 // ------------------------------------------------------------------------------------------
 template <int KS, int TN>
-__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
+__global__ __launch_bounds__(64) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                      const float* __restrict__ wt, const float* __restrict__ bias,
                                                      int B, int N, int d, const int32_t* len) {
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so flat id % 8 labels the L2 a
@@ -390,9 +390,9 @@ extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float*
   V2A_REQUIRE(x != out, "v2a_dwconv: out must not alias x (halo reads)");
   V2A_REQUIRE(ksize == 31, "v2a_dwconv: kernel_size %d (only 31 is built, x3:726)", ksize);
   V2A_REQUIRE(d % 4 == 0 && B > 0 && N > 0, "v2a_dwconv: B=%d N=%d d=%d", B, N, d);
-  constexpr int TN = 8;
+  constexpr int TN = 4;
   const int c4 = d / 4;
-  const int bx = c4 >= 256 ? 256 : ((c4 + 63) / 64) * 64;
+  const int bx = 64;   // one wave = 256 channels: 4x more workgroups than 256-thread blocks (the kernel is latency-bound)
   // grid.y is padded to a multiple of 8 so every XCD label owns a whole range (surplus blocks exit at once)
   const int P = (N + TN - 1) / TN;
   dim3 grid((c4 + bx - 1) / bx, ((P + 7) / 8) * 8, B), block(bx);
