@@ -130,11 +130,18 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
 }
 
-__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
+// NG = 1: 4 waves.  NG = 2: 8 waves, wave group g takes KV tiles g, g+2, ... of the same 64 queries (own LDS
+// ring, shared barrier) and the two partial (m, l, O) states are merged through LDS at the end: twice the
+// waves per SIMD to overlap the softmax VALU work of one wave with the MFMAs / loads of another.
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   constexpr int TK = 64, VLD = 68;
   constexpr int K_ELEMS = TK * 64, V_ELEMS = 64 * VLD;
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (K_ELEMS + V_ELEMS)];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int RING = 2 * (K_ELEMS + V_ELEMS);
+  __shared__ __attribute__((aligned(16))) bf16_t lds_all[NG * RING];
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  bf16_t* lds = lds_all + grp * RING;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 64 + wave * 16;
@@ -190,17 +197,25 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
     }
   };
 
-  const int ntiles = (kvn + TK - 1) / TK;
-  load_tile(0, kregA, vregA);
-  store_tile(lds, kregA, vregA);
-  if (ntiles > 1) load_tile(TK, kregA, vregA);          // tile 1 -> set A (odd tiles live in A, even tiles >= 2 in B)
+  const int ntiles_all = (kvn + TK - 1) / TK;
+  const int nit = (ntiles_all + NG - 1) / NG;             // iterations (barriers) of the whole block
+  const int ntiles = (ntiles_all - grp + NG - 1) / NG;    // tiles of this wave group: global tile = jt * NG + grp
+  if (ntiles > 0) {
+    load_tile(grp * TK, kregA, vregA);
+    store_tile(lds, kregA, vregA);
+  }
+  if (ntiles > 1) load_tile((NG + grp) * TK, kregA, vregA);   // local tile 1 -> set A (odd local tiles in A, even >= 2 in B)
   __syncthreads();
-  for (int jt = 0; jt < ntiles; ++jt) {
+  for (int jt = 0; jt < nit; ++jt) {
+    if (jt >= ntiles) {          // this group ran out of tiles: keep the block's barrier count
+      __syncthreads();
+      continue;
+    }
     const bf16_t* ks = lds + (jt & 1) * (K_ELEMS + V_ELEMS);
     const bf16_t* vt = ks + K_ELEMS;
     if (jt + 2 < ntiles) {
-      if (jt & 1) load_tile((jt + 2) * TK, kregA, vregA);
-      else load_tile((jt + 2) * TK, kregB, vregB);
+      if (jt & 1) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
+      else load_tile(((jt + 2) * NG + grp) * TK, kregB, vregB);
     }
     // ---- S^T = K Q^T : 4 key tiles x 2 k-steps
     f32x4 s[4];
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
       }
     }
     // ---- soft clamp, key mask, online softmax (query on the lane)
-    const int j0 = jt * TK;
+    const int j0 = (jt * NG + grp) * TK;
     const bool partial = j0 + TK > kvn;
     float tmax = -INFINITY;
 #pragma unroll
@@ -271,9 +286,34 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnParams p) {
     }
     __syncthreads();
   }
-  // ---- epilogue: row sum across the 4 key groups, gate, query mask, 8-byte stores
+  // ---- epilogue: row sum across the 4 key groups, merge of the wave groups, gate, query mask, 8-byte stores
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
+  if constexpr (NG == 2) {
+    // group 1 hands (m, l, O) to group 0, lane for lane (same query / d mapping), through its own dead LDS ring
+    float* xch = reinterpret_cast<float*>(lds_all + RING);          // 18 floats x 256 lanes = 18 KB < RING bytes
+    __syncthreads();
+    if (grp == 1) {
+      float* dst = xch + tid;
+      dst[0] = m;
+      dst[256] = l;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(2 + dt * 4 + j) * 256] = o[dt][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float* src = xch + tid;
+    const float m2 = src[0], l2 = src[256];
+    const float mn = fmaxf(m, m2);
+    const float a1 = __expf(m - mn), a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] = o[dt][j] * a1 + src[(2 + dt * 4 + j) * 256] * a2;
+  }
   if (query >= p.Nq) return;
   const int qn = p.q_len ? min(p.q_len[b], p.Nq) : p.Nq;
   float gt = 1.f;
@@ -313,8 +353,10 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
                          a->q_row_stride % 8 == 0 && a->k_row_stride % 8 == 0 && a->v_row_stride % 8 == 0 &&
                          a->q_batch_stride % 8 == 0 && a->k_batch_stride % 8 == 0 && a->v_batch_stride % 8 == 0 &&
                          a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
-    if (aligned)
-      hipLaunchKernelGGL(attn_mfma_kernel, dim3((a->Nq + 63) / 64, a->H, a->B), dim3(256), 0, s, p);
+    if (aligned && a->Nk > 128)
+      hipLaunchKernelGGL(attn_mfma_kernel<2>, dim3((a->Nq + 63) / 64, a->H, a->B), dim3(512), 0, s, p);
+    else if (aligned)
+      hipLaunchKernelGGL(attn_mfma_kernel<1>, dim3((a->Nq + 63) / 64, a->H, a->B), dim3(256), 0, s, p);
     else
       hipLaunchKernelGGL((attn_rowlane_kernel<bf16_t>), grid, block, 0, s, p);
   }
