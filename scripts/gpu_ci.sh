@@ -49,6 +49,23 @@ for s in "$@"; do
              echo "--- small cfg $t: $(grep -E 'timed' gpurun_out/small_$t.log)"
            done; unset V2A_GEMM_SMALL ;;
     bench2) V2A_BENCH_BACKEND=gloo run bench2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 ;;
+    auxw) for t in 0 2; do
+             export V2A_GEMM_AUXW=$t
+             TAILN=0 run auxw_$t 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --shapes
+             echo "--- auxw $t: $(grep -E 'timed' gpurun_out/auxw_$t.log)"; grep -E "geglu,bf16> 1564x10240|resid,f32> 1564x1280x5120|store,bf16> 1564x3088x1280" gpurun_out/auxw_$t.log
+           done; unset V2A_GEMM_AUXW ;;
+    batch) for b in 2 4 8; do
+             TAILN=0 run batch_$b 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --clips-per-gpu $b
+             echo "--- B=$b: $(grep -E 'timed' gpurun_out/batch_$b.log) $(grep -o '"value": [0-9.]*' gpurun_out/batch_$b.log)"
+           done ;;
+    shapes8) run shapes8 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --shapes --single-stream --clips-per-gpu 8 ;;
+    prio) for t in 0 8; do
+             export V2A_GEMM_DBG=$t
+             TAILN=0 run prio_$t 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --shapes
+             echo "--- prio $t: $(grep -E 'timed' gpurun_out/prio_$t.log)"; grep -E "geglu,bf16> 1564x10240|resid,f32> 1564x1280x5120|store,bf16> 1564x3088x1280" gpurun_out/prio_$t.log
+             TAILN=0 run prio8_$t 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --clips-per-gpu 8
+             echo "--- prio $t B=8: $(grep -E 'timed' gpurun_out/prio8_$t.log)"
+           done; unset V2A_GEMM_DBG ;;
     prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
           mkdir -p gpurun_out/prof; cp /tmp/prof/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_multistream.csv ;;
     prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream

@@ -429,7 +429,7 @@ int dispatch_epi(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 // image linear per wave, XOR swizzle applied to the per-lane SOURCE chunk: rule 21 of the CDNA guide),
 // two K tiles stay in flight across the single raw s_barrier of each iteration (counted vmcnt),
 // and no VGPRs or ds_writes are spent on staging.
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN>
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int AUXW = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -511,9 +511,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
       const int g = wave + i * NW;
-      const char* base = g < GA ? ab : wb;                                                  // scalar select
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
-                                       (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
+      if (g < GA)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + goff[i]),
+                                         (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
+      else   // W is streamed: AUXW = 2 marks the loads non-temporal
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + goff[i]),
+                                         (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, AUXW);
     }
   };
 
@@ -572,7 +575,9 @@ template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN>
 int launch_dma(const GemmParams& p, hipStream_t s) {
   constexpr size_t smem = 3 * (size_t)(BM + BN) * 128;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN>;
+  // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
+  // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
+  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, 0>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -680,9 +685,10 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   static const int small = getenv("V2A_GEMM_SMALL") ? atoi(getenv("V2A_GEMM_SMALL")) : -1;
   int cfg;
   if (force >= 0) cfg = force;
-  else if (a->N >= 2048 && ntiles(128, 256) >= 96) cfg = 0;   // wide outputs (QKV, GEGLU): measured best at M ~ 1.5k
+  else if ((a->N >= 2048 && ntiles(128, 256) >= 96) || ntiles(128, 256) >= 200) cfg = 0;   // wide outputs, or large M
   else if (small >= 0) cfg = small;                                     // tuning aid: V2A_GEMM_SMALL
-  else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;   // large M (batched clips)
+  else if (ntiles(128, 128) >= 256) cfg = 1;                            // batched clips, narrow outputs
+  else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;
   else cfg = 3;
   switch (cfg) {
     case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);   // 8 waves, 144 KB LDS, 1 workgroup/CU
