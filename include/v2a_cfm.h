@@ -89,25 +89,6 @@ typedef struct v2a_gemm_args {
    * replaces a separate v2a_rope_inplace(layout 0) pass over the fused [q|k|v|gate] output */
   const float* rope_table;
   int32_t rope_cols, rope_pos_offset;
-  /* fused RMSNorm / AdaptiveRMSNorm (A9/A10: x / max(|x|,1e-12) * sqrt(d) * gamma = r[m] * (x (.) gamma)):
-   *  producer side (fp32 STORE/RESID/GATE_RESID epilogue): besides out, write norm_out[m][n] = T(out * gamma[n]) in
-   *   the compute dtype and add sum_n out^2 of this launch's columns to rss_out[m] (uint64, 2^-32 fixed point: integer
-   *   atomics keep results bit-reproducible; the caller zeroes it).  gamma is a step vector (shares `step` /
-   *   rows_per_batch with `gate`).  Rows >= norm_split_row use norm_gamma_alt / rss_out_alt when norm_gamma_alt != NULL
-   *   (the CFG null half skips cross-attention, so its rows feed a different norm);
-   *  consumer side (any epilogue): acc is multiplied by sqrt(rowscale_dim) / max(sqrt(rowscale_rss[m] * 2^-32), 1e-12)
-   *   before bias, i.e. the GEMM runs on the un-normalised gamma-scaled operand.
-   * Replaces xt RMSNorm / AdaptiveRMSNorm launches (x3:807-816,880-916,935). */
-  void* norm_out;
-  int64_t ld_norm_out;
-  const float* norm_gamma;
-  const float* norm_gamma_alt;
-  int64_t norm_gamma_step_stride, norm_gamma_batch_stride;
-  uint64_t* rss_out;
-  uint64_t* rss_out_alt;
-  int32_t norm_split_row;
-  const uint64_t* rowscale_rss;
-  int32_t rowscale_dim;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
@@ -134,15 +115,6 @@ int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t y_dty
 int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias,
                              int32_t B, int32_t N, int32_t d, int32_t ksize,
                              const int32_t* len, v2a_stream_t stream);
-
-/* Same, plus the fused RMSNorm producer side for the norm that follows the conv in every block (x3:1084,1099,1126):
- * norm_out[b*N+n][:] = T(out * gamma) (T = norm_dtype) and rss_out[b*N+n] += sum_c out^2 (uint64 2^-32 fixed point,
- * pre-zeroed by the caller).  gamma is a step vector indexed by batch b.  See v2a_gemm_args.norm_out. */
-int v2a_dwconv_silu_residual_norm(const float* x, float* out, const float* wt, const float* bias,
-                                  int32_t B, int32_t N, int32_t d, int32_t ksize, const int32_t* len,
-                                  void* norm_out, int32_t norm_dtype, const float* gamma, const int32_t* step,
-                                  int64_t gamma_step_stride, int64_t gamma_batch_stride, uint64_t* rss_out,
-                                  v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Rotary embedding applied in place to `nheads` consecutive 64-wide heads of every row

@@ -225,93 +225,6 @@ def test_gemm_rejects_bad_args(L):
         L.gemm([(a, 40, 40)], w, out, M=4, N=16, compute=L.F32)
 
 
-# ------------------------------------------------------------------- fused RMSNorm (producer / consumer)
-def _rss_to_float(rss):
-    return rss.cpu().double() / 2.0 ** 32
-
-
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_gemm_fused_norm_producer_consumer(L, mode):
-    """out = resid + A W^T (RESID epilogue) also emits the gamma-scaled operand + row sums of squares of TWO norm
-    sites split by row (CFG cond / null halves); a consumer GEMM with rowscale then equals rmsnorm(out, gamma) W2^T + b."""
-    M, d, K, N2, split = 150, 128, 64, 96, 88
-    cd, comp, tol = (torch.float32, L.F32, 3e-5) if mode == "fp32" else (torch.bfloat16, L.BF16, 3e-2)
-    a = torch.randn(M, K, generator=_g(1)).to(cd)
-    w = (torch.randn(d, K, generator=_g(2)) / math.sqrt(K)).to(cd)
-    resid = torch.randn(M, d, generator=_g(3))
-    gam = 1 + 0.2 * torch.randn(2, d, generator=_g(4))
-    w2 = (torch.randn(N2, d, generator=_g(5)) / math.sqrt(d)).to(cd)
-    b2 = torch.randn(N2, generator=_g(6))
-    out = torch.empty(M, d, device=DEV)
-    hn = torch.empty(M, d, dtype=cd, device=DEV)
-    rss = torch.zeros(2, M, dtype=torch.int64, device=DEV)
-    gd = gam.to(DEV)
-    L.gemm([(a.to(DEV), K, K)], w.to(DEV), out, M=M, N=d, compute=comp, epilogue=L.EPI_RESID, resid=resid.to(DEV),
-           norm_out=hn, ld_norm_out=d, norm_gamma=gd[0], norm_gamma_alt=gd[1], rss_out=rss[0], rss_out_alt=rss[1], norm_split_row=split)
-    ref_out = resid.double() + a.double() @ w.double().t()
-    torch.testing.assert_close(out.cpu().double(), ref_out, atol=1e-4 if mode == "bf16" else 2e-5, rtol=1e-5)
-    o = out.cpu()
-    gsel = torch.where(torch.arange(M)[:, None] < split, gam[0][None], gam[1][None])
-    torch.testing.assert_close(hn.float().cpu(), (o * gsel), atol=tol, rtol=tol)
-    r = _rss_to_float(rss)
-    ss = (o.double() ** 2).sum(-1)
-    torch.testing.assert_close(r[0][:split], ss[:split], rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(r[1][split:], ss[split:], rtol=1e-5, atol=1e-6)
-    assert float(r[0][split:].abs().max()) == 0 and float(r[1][:split].abs().max()) == 0
-    # consumer on the first site's rows
-    y = torch.empty(split, N2, device=DEV)
-    L.gemm([(hn, d, d)], w2.to(DEV), y, M=split, N=N2, compute=comp, bias=b2.to(DEV), rowscale_rss=rss[0], rowscale_dim=d)
-    ref = torch.nn.functional.linear(O.rmsnorm(o[:split], gam[0]).to(cd).float(), w2.float(), b2)
-    torch.testing.assert_close(y.cpu(), ref, atol=tol * 2, rtol=tol)
-
-
-def test_gemm_geglu_with_rowscale(L):
-    from v2a_amd.dit import _FF
-    M, d = 70, 128
-    sd = {"ff.ff.0.proj.weight": torch.randn(8 * d, d, generator=_g(1)) / math.sqrt(d), "ff.ff.0.proj.bias": 0.1 * torch.randn(8 * d, generator=_g(2)),
-          "ff.ff.2.weight": torch.randn(d, 4 * d, generator=_g(3)) / math.sqrt(4 * d), "ff.ff.2.bias": 0.1 * torch.randn(d, generator=_g(4))}
-    F = _FF(sd, "ff", d, torch.float32, DEV)
-    x = 3.0 * torch.randn(M, d, generator=_g(5))
-    g = 1 + 0.1 * torch.randn(d, generator=_g(6))
-    rss = ((x.double() ** 2).sum(-1) * 2.0 ** 32).to(torch.int64).to(DEV)
-    out = torch.empty(M, 4 * d, device=DEV)
-    L.gemm([((x * g).to(DEV), d, d)], F.w1, out, M=M, N=8 * d, compute=L.F32, epilogue=L.EPI_GEGLU, bias=F.b1, ldo=4 * d,
-           rowscale_rss=rss, rowscale_dim=d)
-    h = torch.nn.functional.linear(O.rmsnorm(x, g), sd["ff.ff.0.proj.weight"], sd["ff.ff.0.proj.bias"])
-    a_, g_ = h.chunk(2, -1)
-    torch.testing.assert_close(out.cpu(), a_ * torch.nn.functional.gelu(g_), atol=3e-5, rtol=2e-5)
-
-
-@pytest.mark.parametrize("d,dt", [(128, torch.float32), (192, torch.bfloat16), (1280, torch.bfloat16)])
-def test_dwconv_fused_norm(L, d, dt):
-    """conv + residual also emits the next RMSNorm's operand (x * gamma) and row sums of squares; d = 192 leaves lanes idle."""
-    B, N = 2, 37
-    lens = [37, 20]
-    x = torch.randn(B, N, d, generator=_g(d))
-    w = torch.randn(d, 1, 31, generator=_g(d + 1)) / math.sqrt(31)
-    bias = 0.1 * torch.randn(d, generator=_g(d + 2))
-    gam = 1 + 0.2 * torch.randn(3, B, d, generator=_g(d + 3))          # step table: (S, B, d)
-    mask = O.lens_to_mask(torch.tensor(lens), N)
-    ref = O.depthwise_conv(x, w, bias, mask) + x
-    out = torch.empty(B, N, d, device=DEV)
-    hn = torch.empty(B * N, d, dtype=dt, device=DEV)
-    rss = torch.zeros(B * N, dtype=torch.int64, device=DEV)
-    step = torch.tensor([2], dtype=torch.int32, device=DEV)
-    L.dwconv(x.to(DEV), out, w[:, 0, :].t().contiguous().to(DEV), bias.to(DEV), B=B, N=N, d=d, ksize=31,
-             lens=torch.tensor(lens, dtype=torch.int32, device=DEV), norm_out=hn, gamma=gam.to(DEV), step=step,
-             gamma_step_stride=B * d, gamma_batch_stride=d, rss_out=rss)
-    torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
-    tol = 1e-5 if dt == torch.float32 else 2e-2
-    torch.testing.assert_close(hn.float().cpu().reshape(B, N, d), out.cpu() * gam[2][:, None, :], atol=tol, rtol=tol)
-    torch.testing.assert_close(_rss_to_float(rss).reshape(B, N), (out.cpu().double() ** 2).sum(-1), rtol=1e-5, atol=1e-6)
-    # bit-reproducible accumulation (integer atomics): a second launch gives the identical rss
-    rss2 = torch.zeros_like(rss)
-    L.dwconv(x.to(DEV), out, w[:, 0, :].t().contiguous().to(DEV), bias.to(DEV), B=B, N=N, d=d, ksize=31,
-             lens=torch.tensor(lens, dtype=torch.int32, device=DEV), norm_out=hn, gamma=gam.to(DEV), step=step,
-             gamma_step_stride=B * d, gamma_batch_stride=d, rss_out=rss2)
-    assert torch.equal(rss, rss2)
-
-
 # ----------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, gate, kv_len, q_len, clamp=50.0):
     """q (B,H,Nq,64) etc. fp32 CPU."""

@@ -39,10 +39,6 @@ class GemmArgs(C.Structure):
         ("gate", C.c_void_p), ("step", C.c_void_p),
         ("gate_step_stride", C.c_int64), ("gate_batch_stride", C.c_int64), ("rows_per_batch", C.c_int32),
         ("rope_table", C.c_void_p), ("rope_cols", C.c_int32), ("rope_pos_offset", C.c_int32),
-        ("norm_out", C.c_void_p), ("ld_norm_out", C.c_int64), ("norm_gamma", C.c_void_p), ("norm_gamma_alt", C.c_void_p),
-        ("norm_gamma_step_stride", C.c_int64), ("norm_gamma_batch_stride", C.c_int64),
-        ("rss_out", C.c_void_p), ("rss_out_alt", C.c_void_p), ("norm_split_row", C.c_int32),
-        ("rowscale_rss", C.c_void_p), ("rowscale_dim", C.c_int32),
     ]
 
 
@@ -60,7 +56,7 @@ class AttnArgs(C.Structure):
 
 
 EXPORTS = [
-    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_rmsnorm", "v2a_dwconv_silu_residual", "v2a_dwconv_silu_residual_norm",
+    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
 ]
@@ -88,7 +84,6 @@ def _declare(lib):
     lib.v2a_attention.argtypes = [C.POINTER(AttnArgs), vp]
     lib.v2a_rmsnorm.argtypes = [vp, i64, vp, i64, i32, i64, i32, vp, vp, i64, i64, i32, vp]
     lib.v2a_dwconv_silu_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
-    lib.v2a_dwconv_silu_residual_norm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i64, i64, vp, vp]
     lib.v2a_rope_inplace.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, i32, vp]
     lib.v2a_linear_small.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, vp]
     lib.v2a_fill_registers.argtypes = [vp, i64, vp, i32, i32, i32, vp]
@@ -187,9 +182,7 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 
 def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
-         out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0,
-         norm_out=None, ld_norm_out=0, norm_gamma=None, norm_gamma_alt=None, norm_gamma_step_stride=0,
-         norm_gamma_batch_stride=0, rss_out=None, rss_out_alt=None, norm_split_row=0, rowscale_rss=None, rowscale_dim=0):
+         out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
     g = GemmArgs()
     for i, (t, lda, k) in enumerate(a_segs):
@@ -218,11 +211,6 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.rows_per_batch = rows_per_batch
     g.rope_table = _p(rope_table)
     g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
-    g.norm_out, g.ld_norm_out = _p(norm_out), ld_norm_out
-    g.norm_gamma, g.norm_gamma_alt = _p(norm_gamma), _p(norm_gamma_alt)
-    g.norm_gamma_step_stride, g.norm_gamma_batch_stride = norm_gamma_step_stride, norm_gamma_batch_stride
-    g.rss_out, g.rss_out_alt, g.norm_split_row = _p(rss_out), _p(rss_out_alt), norm_split_row
-    g.rowscale_rss, g.rowscale_dim = _p(rowscale_rss), rowscale_dim
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
@@ -241,18 +229,10 @@ def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch
                                       stream_ptr()))
 
 
-def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm_out=None, gamma=None, step=None, gamma_step_stride=0,
-           gamma_batch_stride=0, rss_out=None):
-    if norm_out is None:
-        _launch("dwconv", 2.0 * B * N * d * ksize, B * N * d * 8,
-                lambda: lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
-                                                       B, N, d, ksize, _p(lens), stream_ptr()))
-    else:
-        _launch("dwconv+norm", 2.0 * B * N * d * ksize, B * N * d * (8 + norm_out.element_size()),
-                lambda: lib().v2a_dwconv_silu_residual_norm(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
-                                                            B, N, d, ksize, _p(lens), norm_out.data_ptr(), dt_code(norm_out.dtype),
-                                                            gamma.data_ptr(), _p(step), gamma_step_stride, gamma_batch_stride,
-                                                            rss_out.data_ptr(), stream_ptr()))
+def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None):
+    _launch("dwconv", 2.0 * B * N * d * ksize, B * N * d * 8,
+            lambda: lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                   B, N, d, ksize, _p(lens), stream_ptr()))
 
 
 def rope(qk, *, rows, row_stride, nheads, rows_per_batch, pos_offset, table, layout):

@@ -11,7 +11,6 @@
 #include "v2a_common.h"
 #include <stdlib.h>
 #include <type_traits>
-#include <math.h>
 
 namespace {
 
@@ -34,16 +33,6 @@ struct GemmParams {
   const int32_t* step;
   int64_t gss, gbs;
   int32_t rpb;
-  // fused RMSNorm (see include/v2a_cfm.h): producer side writes the gamma-scaled operand + row sum of squares,
-  // consumer side scales the accumulator by sqrt(d) / ||x_row||
-  void* norm_out;
-  int64_t ldn;
-  const float* ngamma[2];
-  int64_t ngss, ngbs;
-  unsigned long long* rss_out[2];
-  int32_t norm_split;
-  const unsigned long long* rs_rss;
-  float rs_sqrt_d;
   const float* rope;     // cos/sin table [pos][32][2] or null: rotate interleaved pairs of columns < rope_cols (STORE epilogue)
   int32_t rope_cols, rope_pos_off;
   int32_t vec_epi;  // all epilogue pointers / strides allow 16-byte row pieces
@@ -126,16 +115,8 @@ template <typename T, bool A_F32, int ROWS> struct StageSel;
 template <bool A_F32, int ROWS> struct StageSel<bf16_t, A_F32, ROWS> { using type = StageBf16<ROWS, A_F32>; };
 template <bool A_F32, int ROWS> struct StageSel<float, A_F32, ROWS> { using type = StageF32<ROWS>; };
 
-// row sums of squares travel as 64-bit fixed point (2^-32 units): integer atomics are associative, so the
-// accumulated value -- and everything downstream -- is bit-identical from run to run
-__device__ __forceinline__ unsigned long long rss_fix(float ss) { return (unsigned long long)(ss * 4294967296.0f); }
-__device__ __forceinline__ float row_scale(const unsigned long long* rss, int64_t m, float sqrt_d) {
-  const float ss = (float)rss[m] * (1.0f / 4294967296.0f);
-  return sqrt_d / fmaxf(sqrtf(ss), 1e-12f);     // F.normalize eps
-}
-
 // ---- shared epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + j ------------------
-template <int EPI, typename OutT, typename NT, int TM, int TN, int WM, int WN>
+template <int EPI, typename OutT, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                               int lr, int lq) {
   OutT* out = reinterpret_cast<OutT*>(p.out);
@@ -144,32 +125,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int m = m0 + wm * WM + i * 16 + lq * 4 + jj;
-      const bool mok = m < p.M;
-      const int mc = mok ? m : p.M - 1;
+      if (m >= p.M) continue;
       const float* gvec = nullptr;
-      if constexpr (EPI == V2A_EPI_GATE_RESID) gvec = step_vec(p.gate, p.step, p.gss, p.gbs, mc / p.rpb);
-      const float rs = p.rs_rss ? row_scale(p.rs_rss, mc, p.rs_sqrt_d) : 1.0f;
+      if constexpr (EPI == V2A_EPI_GATE_RESID) gvec = step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb);
       if constexpr (EPI == V2A_EPI_GEGLU) {
-        if (!mok) continue;
 #pragma unroll
         for (int j = 0; j < TN; j += 2) {
           const int n = n0 + wn * WN + j * 16 + lr;  // packed row index of the value
           if (n >= p.N) continue;
-          float v = acc[i][j][jj] * rs, g = acc[i][j + 1][jj] * rs;
+          float v = acc[i][j][jj], g = acc[i][j + 1][jj];
           if (p.bias) { v += p.bias[n]; g += p.bias[n + 16]; }
           const int oc = ((n0 + wn * WN) >> 1) + (j >> 1) * 16 + lr;
           const float ge = sizeof(OutT) == 2 ? gelu_fast_f(g) : gelu_erf_f(g);
           out[(int64_t)m * p.ldo + oc] = from_f32<OutT>(v * ge);
         }
       } else {
-        const int alt = (p.norm_out && mc >= p.norm_split) ? 1 : 0;
-        const float* ngv = p.norm_out ? step_vec(p.ngamma[alt], p.step, p.ngss, p.ngbs, mc / p.rpb) : nullptr;
-        float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + wn * WN + j * 16 + lr;
-          if (n >= p.N || !mok) continue;
-          float v = acc[i][j][jj] * rs;
+          if (n >= p.N) continue;
+          float v = acc[i][j][jj];
           if (p.bias) v += p.bias[n];
           if constexpr (EPI == V2A_EPI_SIGMOID) v = sigmoid_f(v);
           if constexpr (EPI == V2A_EPI_RESID) v += p.resid[(int64_t)m * p.ldr + n];
@@ -177,17 +152,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           out[(int64_t)m * p.ldo + n] = from_f32<OutT>(v);
           if constexpr (sizeof(OutT) == 4) {
             if (p.out2) p.out2[(int64_t)m * p.ldo2 + n] = (bf16_t)v;
-            if (p.norm_out) {
-              reinterpret_cast<NT*>(p.norm_out)[(int64_t)m * p.ldn + n] = from_f32<NT>(v * ngv[n]);
-              ss += v * v;
-            }
-          }
-        }
-        if constexpr (sizeof(OutT) == 4) {
-          if (p.norm_out) {     // the 16 lanes lr = 0..15 of a quarter-wave hold 16 columns of this row (all lanes get here)
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            if (lr == 0 && mok) atomicAdd(p.rss_out[alt] + m, rss_fix(ss));
           }
         }
       }
@@ -230,13 +194,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     for (int r = r0; r < WM; r += RPI) {
       const int m = m_base + r;
       if (m >= p.M || n >= p.N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
-      f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
-      if (p.rs_rss) {
-        const float rs = row_scale(p.rs_rss, m, p.rs_sqrt_d);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] *= rs; g[e] *= rs; }
-      }
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
       OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
       if constexpr (sizeof(OutT) == 2) {
         bf16x4 o;
@@ -261,15 +220,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
 #pragma unroll
     for (int r = r0; r < WM; r += RPI) {
       const int m = m_base + r;
-      const bool act = m < p.M && full;
-      if (!act && !p.norm_out) continue;          // with a fused norm every lane stays for the row reduction
-      const int mc = m < p.M ? m : p.M - 1;
+      if (m >= p.M || !full) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
-      if (p.rs_rss) {
-        const float rs = row_scale(p.rs_rss, mc, p.rs_sqrt_d);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= rs;
-      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += bv[e];
       if constexpr (EPI == V2A_EPI_SIGMOID) {
@@ -289,54 +241,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         }
       }
       if constexpr (EPI == V2A_EPI_RESID) {
-        if (act) {
-          const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rs[e];
-        }
+        for (int e = 0; e < 4; ++e) v[e] += rs[e];
       }
       if constexpr (EPI == V2A_EPI_GATE_RESID) {
-        if (act) {
-          const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
-          const f32x4 gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+        const f32x4 gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
-        }
+        for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
       }
       if constexpr (sizeof(OutT) == 2) {
-        if (act) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x4*>(out + (int64_t)m * p.ldo + n) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldo + n) = v;
+        if (p.out2) {
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x4*>(out + (int64_t)m * p.ldo + n) = o;
-        }
-      } else {
-        if (act) {
-          *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldo + n) = v;
-          if (p.out2) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(p.out2 + (int64_t)m * p.ldo2 + n) = o;
-          }
-        }
-        if (p.norm_out) {
-          // fused RMSNorm producer: operand = x * gamma (bf16), row sum of squares over this wave's WN columns
-          const int alt = mc >= p.norm_split ? 1 : 0;
-          float ss = 0.f;
-          if (act) {
-            const f32x4 ng = *reinterpret_cast<const f32x4*>(step_vec(p.ngamma[alt], p.step, p.ngss, p.ngbs, m / p.rpb) + n);
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = (bf16_t)(v[e] * ng[e]);
-              ss += v[e] * v[e];
-            }
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.norm_out) + (int64_t)m * p.ldn + n) = o;
-          }
-#pragma unroll
-          for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // the LPR lanes of a row are adjacent
-          if ((lane % LPR) == 0 && m < p.M) atomicAdd(p.rss_out[alt] + m, rss_fix(ss));
+          *reinterpret_cast<bf16x4*>(p.out2 + (int64_t)m * p.ldo2 + n) = o;
         }
       }
     }
@@ -450,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  gemm_epilogue<EPI, OutT, T, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
+  gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
 }
 
 template <typename T, bool A_F32, int EPI, typename OutT, int BM, int BN>
@@ -641,7 +567,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     float* tile = reinterpret_cast<float*>(smem_raw) + wave * (WM * (WN + 4));
     gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane);
   } else {
-    gemm_epilogue<EPI, OutT, bf16_t, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
+    gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
   }
 }
 
@@ -733,29 +659,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     if (a->resid) ok = ok && al16(a->resid) && a->ldr % 4 == 0;
     if (a->gate) ok = ok && al16(a->gate) && a->gate_step_stride % 4 == 0 && a->gate_batch_stride % 4 == 0;
     if (a->out_bf16) ok = ok && ((uintptr_t)a->out_bf16 & 7) == 0 && a->ld_out_bf16 % 4 == 0;
-    if (a->norm_out) ok = ok && ((uintptr_t)a->norm_out & 7) == 0 && a->ld_norm_out % 4 == 0 && al16(a->norm_gamma) &&
-                          (!a->norm_gamma_alt || al16(a->norm_gamma_alt)) && a->norm_gamma_step_stride % 4 == 0 &&
-                          a->norm_gamma_batch_stride % 4 == 0 && a->N % 64 == 0;
     p.vec_epi = ok ? 1 : 0;
   }
-  p.norm_out = a->norm_out;
-  p.ldn = a->ld_norm_out;
-  p.ngamma[0] = a->norm_gamma;
-  p.ngamma[1] = a->norm_gamma_alt ? a->norm_gamma_alt : a->norm_gamma;
-  p.ngss = a->norm_gamma_step_stride;
-  p.ngbs = a->norm_gamma_batch_stride;
-  p.rss_out[0] = reinterpret_cast<unsigned long long*>(a->rss_out);
-  p.rss_out[1] = reinterpret_cast<unsigned long long*>(a->rss_out_alt ? a->rss_out_alt : a->rss_out);
-  p.norm_split = a->norm_gamma_alt ? a->norm_split_row : a->M;
-  p.rs_rss = reinterpret_cast<const unsigned long long*>(a->rowscale_rss);
-  p.rs_sqrt_d = a->rowscale_dim > 0 ? sqrtf((float)a->rowscale_dim) : 0.f;
-  if (a->norm_out) {
-    V2A_REQUIRE((a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID || a->epilogue == V2A_EPI_STORE) &&
-                    a->out_dtype == V2A_F32 && a->norm_gamma && a->rss_out && ((uintptr_t)a->rss_out & 7) == 0,
-                "v2a_gemm: fused norm output needs an fp32 STORE/RESID/GATE_RESID epilogue, norm_gamma and an 8-byte aligned rss_out");
-    V2A_REQUIRE(a->N % 64 == 0 || a->a_dtype == V2A_F32 || a->compute_dtype == V2A_F32, "v2a_gemm: fused norm output needs N %% 64 == 0 (N=%d)", a->N);
-  }
-  if (a->rowscale_rss) V2A_REQUIRE(a->rowscale_dim > 0 && ((uintptr_t)a->rowscale_rss & 7) == 0, "v2a_gemm: rowscale_rss needs rowscale_dim > 0");
   p.rope = a->rope_table;
   p.rope_cols = a->rope_cols;
   p.rope_pos_off = a->rope_pos_offset;

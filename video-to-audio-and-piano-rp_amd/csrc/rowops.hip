@@ -65,19 +65,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // TN + k - 1 input rows once (float4 each) and scatters every input into the <= k outputs
 // that use it; the k tap weights (float4 each, [k][d] layout -> coalesced) stay in registers.
 // ------------------------------------------------------------------------------------------
-struct ConvNorm {          // optional fused RMSNorm producer (see v2a_gemm_args.norm_out)
-  void* hn;                // [B*N][d] operand = T(out * gamma), T = compute dtype
-  int32_t hn_dtype;
-  const float* gamma;
-  const int32_t* step;
-  int64_t gss, gbs;
-  unsigned long long* rss; // [B*N] row sum of squares, 2^-32 fixed point, pre-zeroed
-};
-
 template <int KS, int TN>
 __global__ __launch_bounds__(64) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                    const float* __restrict__ wt, const float* __restrict__ bias,
-                                                    int B, int N, int d, const int32_t* len, ConvNorm nm) {
+                                                     const float* __restrict__ wt, const float* __restrict__ bias,
+                                                     int B, int N, int d, const int32_t* len) {
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so flat id % 8 labels the L2 a
   // block will use.  Give each label a contiguous range of position tiles (all channel blocks of a tile
   // together): the k-1 halo rows a tile shares with its neighbours then hit in that XCD's L2 instead of
@@ -89,20 +80,18 @@ __global__ __launch_bounds__(64) void dwconv_kernel(const float* __restrict__ x,
   const int ptile = xcd * per + slot / CB, cblk = slot % CB;
   const int b = blockIdx.z;
   const int c4 = cblk * blockDim.x + threadIdx.x;        // float4 channel group
-  if (ptile >= P || slot >= per * CB) return;            // whole wave
-  const bool cok = c4 * 4 < d;                           // lanes past d stay for the wave reduction
-  const int cc = cok ? c4 : 0;
+  if (ptile >= P || slot >= per * CB || c4 * 4 >= d) return;
   const int n0 = ptile * TN;
   const int L = len ? min(len[b], N) : N;
   constexpr int HALF = KS / 2;
   f32x4 w[KS];
 #pragma unroll
-  for (int j = 0; j < KS; ++j) w[j] = *reinterpret_cast<const f32x4*>(wt + (int64_t)j * d + 4 * cc);
+  for (int j = 0; j < KS; ++j) w[j] = *reinterpret_cast<const f32x4*>(wt + (int64_t)j * d + 4 * c4);
   f32x4 acc[TN];
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * cc);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
 #pragma unroll
   for (int t = 0; t < TN; ++t) acc[t] = bv;
-  const float* xb = x + (int64_t)b * N * d + 4 * cc;
+  const float* xb = x + (int64_t)b * N * d + 4 * c4;
   // input position p = n0 - HALF + i contributes to output t with tap j = p - (n0 + t) + HALF = i - t
 #pragma unroll
   for (int i = 0; i < TN + KS - 1; ++i) {
@@ -122,9 +111,7 @@ __global__ __launch_bounds__(64) void dwconv_kernel(const float* __restrict__ x,
       }
     }
   }
-  float* ob = out + (int64_t)b * N * d + 4 * cc;
-  f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-  if (nm.hn) gv = *reinterpret_cast<const f32x4*>(step_vec(nm.gamma, nm.step, nm.gss, nm.gbs, b) + 4 * cc);
+  float* ob = out + (int64_t)b * N * d + 4 * c4;
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int n = n0 + t;
@@ -134,27 +121,7 @@ __global__ __launch_bounds__(64) void dwconv_kernel(const float* __restrict__ x,
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] += silu_f(acc[t][j]);
     }
-    if (cok) *reinterpret_cast<f32x4*>(ob + (int64_t)n * d) = o;
-    if (nm.hn) {
-      const int64_t row = (int64_t)b * N + n;
-      float ss = 0.f;
-      if (cok) {
-        ss = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
-        if (nm.hn_dtype == V2A_BF16) {
-          bf16x4 h;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) h[j] = (bf16_t)(o[j] * gv[j]);
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(nm.hn) + row * d + 4 * cc) = h;
-        } else {
-          f32x4 h;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) h[j] = o[j] * gv[j];
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(nm.hn) + row * d + 4 * cc) = h;
-        }
-      }
-      ss = wave_sum(ss);
-      if (threadIdx.x == 0) atomicAdd(nm.rss + row, (unsigned long long)(ss * 4294967296.0f));
-    }
+    *reinterpret_cast<f32x4*>(ob + (int64_t)n * d) = o;
   }
 }
 
@@ -417,8 +384,8 @@ extern "C" int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, in
   return v2a_check_launch("v2a_rmsnorm");
 }
 
-static int dwconv_launch(const float* x, float* out, const float* wt, const float* bias, int32_t B, int32_t N, int32_t d,
-                         int32_t ksize, const int32_t* len, const ConvNorm& nm, v2a_stream_t stream) {
+extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias, int32_t B,
+                                        int32_t N, int32_t d, int32_t ksize, const int32_t* len, v2a_stream_t stream) {
   V2A_REQUIRE(x && out && wt && bias, "v2a_dwconv: null pointer");
   V2A_REQUIRE(x != out, "v2a_dwconv: out must not alias x (halo reads)");
   V2A_REQUIRE(ksize == 31, "v2a_dwconv: kernel_size %d (only 31 is built, x3:726)", ksize);
@@ -429,27 +396,8 @@ static int dwconv_launch(const float* x, float* out, const float* wt, const floa
   // grid.y is padded to a multiple of 8 so every XCD label owns a whole range (surplus blocks exit at once)
   const int P = (N + TN - 1) / TN;
   dim3 grid((c4 + bx - 1) / bx, ((P + 7) / 8) * 8, B), block(bx);
-  hipLaunchKernelGGL((dwconv_kernel<31, TN>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, nm);
+  hipLaunchKernelGGL((dwconv_kernel<31, TN>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
   return v2a_check_launch("v2a_dwconv_silu_residual");
-}
-
-extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias, int32_t B,
-                                        int32_t N, int32_t d, int32_t ksize, const int32_t* len, v2a_stream_t stream) {
-  ConvNorm nm{};
-  return dwconv_launch(x, out, wt, bias, B, N, d, ksize, len, nm, stream);
-}
-
-extern "C" int v2a_dwconv_silu_residual_norm(const float* x, float* out, const float* wt, const float* bias, int32_t B,
-                                             int32_t N, int32_t d, int32_t ksize, const int32_t* len, void* norm_out,
-                                             int32_t norm_dtype, const float* gamma, const int32_t* step,
-                                             int64_t gamma_step_stride, int64_t gamma_batch_stride, uint64_t* rss_out,
-                                             v2a_stream_t stream) {
-  V2A_REQUIRE(norm_out && gamma && rss_out, "v2a_dwconv_norm: null pointer");
-  V2A_REQUIRE(norm_dtype == V2A_F32 || norm_dtype == V2A_BF16, "v2a_dwconv_norm: dtype %d", norm_dtype);
-  V2A_REQUIRE(gamma_step_stride % 4 == 0 && gamma_batch_stride % 4 == 0 && ((uintptr_t)gamma & 15) == 0 &&
-                  ((uintptr_t)norm_out & 15) == 0 && ((uintptr_t)rss_out & 7) == 0, "v2a_dwconv_norm: alignment");
-  ConvNorm nm{norm_out, norm_dtype, gamma, step, gamma_step_stride, gamma_batch_stride, reinterpret_cast<unsigned long long*>(rss_out)};
-  return dwconv_launch(x, out, wt, bias, B, N, d, ksize, len, nm, stream);
 }
 
 extern "C" int v2a_rope_inplace(void* qk, int32_t dtype, int64_t rows, int64_t row_stride, int32_t nheads,

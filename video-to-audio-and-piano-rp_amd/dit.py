@@ -228,9 +228,6 @@ class DiTEngine:
                 p["shadow"][p[name].data_ptr()] = torch.empty_like(p[name], dtype=cd)
             for sk in p["skips"]:
                 p["shadow"][sk.data_ptr()] = torch.empty_like(sk, dtype=cd)
-        # row sums of squares of every norm site (uint64 2^-32 fixed point; slots: audio attn / cross-attn / ff,
-        # text attn / ff, frames attn / ff; last row: final norm), zeroed once per evaluation
-        p["rss_all"] = torch.zeros(c.depth * 7 + 1, rows, dtype=torch.int64, device=dev)
         p["q2"] = e(B * N, W0["a_attn2"].n_pad, dt=cd)
         inner = c.heads * c.dim_head
         p["ctx_kv"] = e(B * nc, 2 * c.depth * inner, dt=cd)
@@ -267,31 +264,17 @@ class DiTEngine:
         s = self._sh(buf)
         return buf if s is None else s
 
-    def _site(self, layer, slot):
-        """rss vector (rows,) of norm site `slot` of `layer` (see setup); layer = depth -> final norm."""
-        return self.plan["rss_all"][layer * 7 + slot]
+    def _norm_plain(self, x, hn, rows, d, g):
+        L.rmsnorm(x, hn, rows=rows, d=d, gamma=g)
 
-    def _g_plain(self, g):
-        return dict(gamma=g, step=None, step_stride=0, batch_stride=0)
-
-    def _g_ada(self, layer, slot):
-        """(to_gamma(c) + 1) of AdaptiveRMSNorm `slot` (0 attn, 1 cross-attn, 2 ff) from the modulation table."""
+    def _norm_ada(self, x, hn, rows, d, layer, slot):
         p = self.plan
-        ss = p["norm_tab"].stride(0)
         tab = p["norm_tab"][0, layer, slot]
+        ss = p["norm_tab"].stride(0)
         if p["per_sample_t"]:
-            return dict(gamma=tab, step=None, step_stride=0, batch_stride=ss)
-        return dict(gamma=tab, step=p["step"], step_stride=ss, batch_stride=0)
-
-    def _norm_kw(self, hn, d, g, rss, g_alt=None, rss_alt=None, split=0):
-        """GEMM-epilogue arguments of a fused norm PRODUCER (x3 norm sites; see v2a_gemm_args.norm_out)."""
-        kw = dict(norm_out=hn, ld_norm_out=d, norm_gamma=g["gamma"], norm_gamma_step_stride=g["step_stride"],
-                  norm_gamma_batch_stride=g["batch_stride"], rss_out=rss, rows_per_batch=self.plan["N"])
-        if g["step"] is not None:
-            kw["step"] = g["step"]
-        if g_alt is not None:
-            kw.update(norm_gamma_alt=g_alt["gamma"], rss_out_alt=rss_alt, norm_split_row=split)
-        return kw
+            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, gamma_batch_stride=ss, rows_per_batch=p["N"])
+        else:
+            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, step=p["step"], gamma_step_stride=ss, rows_per_batch=p["N"])
 
     def _gate_kw(self, layer, slot):
         p = self.plan
@@ -301,18 +284,16 @@ class DiTEngine:
             return dict(gate=tab, gate_batch_stride=ss, rows_per_batch=p["N"])
         return dict(gate=tab, step=p["step"], gate_step_stride=ss, rows_per_batch=p["N"])
 
-    def _self_attn(self, A: _Attn, x, s, nseq, d, out_kw, rs):
-        """x += epilogue(to_out(attend(rope(q), rope(k), v) * sigmoid(gate))).  The operand hn_s holds x (.) gamma of the
-        preceding norm and `rs` its row sums of squares: the QKV GEMM applies the RMSNorm row scale in its epilogue."""
+    def _self_attn(self, A: _Attn, x, s, nseq, d, out_kw):
+        """x += epilogue(to_out(attend(rope(q), rope(k), v) * sigmoid(gate))), operand hn_s already normed."""
         p = self.plan
         N, rows = p["N"], nseq * p["N"]
         hn, qkv, ao = p[f"hn_{s}"], p[f"qkv_{s}"], p[f"ao_{s}"]
-        nk = dict(rowscale_rss=rs, rowscale_dim=d)
         if self._fuse_rope:       # RoPE of the q and k heads inside the QKV GEMM epilogue
             L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad,
-                   rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **nk)
+                   rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N)
         else:
-            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad, **nk)
+            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad)
             L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
                    table=p["rope"], layout=self.rope_layout)
         es = qkv.element_size()
@@ -326,31 +307,26 @@ class DiTEngine:
                     scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.cdc)
         L.gemm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, compute=self.cdc, resid=x, ldo=d, ldr=d, **out_kw)
 
-    def _ff(self, Fw: _FF, x, s, nseq, d, out_kw, rs):
+    def _ff(self, Fw: _FF, x, s, nseq, d, out_kw):
         p = self.plan
         rows = nseq * p["N"]
         hn, ffh = p[f"hn_{s}"], p[f"ffh_{s}"]
         L.gemm([(hn, d, d)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, compute=self.cdc, epilogue=L.EPI_GEGLU,
-               bias=Fw.b1, ldo=Fw.inner, rowscale_rss=rs, rowscale_dim=d)
+               bias=Fw.b1, ldo=Fw.inner)
         L.gemm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, compute=self.cdc, bias=Fw.b2, resid=x,
                ldo=d, ldr=d, out_bf16=self._sh(x), **out_kw)
 
-    def _side_block(self, ly, s, li, src, dst, nseq, d):
-        """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward.  Both RMSNorms are
-        fused: the conv and the attention out-projection write the gamma-scaled operand + row sums of squares."""
+    def _side_block(self, ly, s, src, dst, nseq, d):
+        """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward."""
         p = self.plan
-        N = p["N"]
+        N, rows = p["N"], nseq * p["N"]
         lens = p["seq_len"] if p["ragged"] else None
         cv = ly[f"{s}_conv"]
-        hn = p[f"hn_{s}"]
-        s1, s2 = (3, 4) if s == "t" else (5, 6)
-        g1 = self._g_plain(ly[f"{s}_g1"])
-        L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens, norm_out=hn, gamma=g1["gamma"],
-                 rss_out=self._site(li, s1))
-        self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d,
-                        dict(epilogue=L.EPI_RESID, **self._norm_kw(hn, d, self._g_plain(ly[f"{s}_g2"]), self._site(li, s2))),
-                        rs=self._site(li, s1))
-        self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID), rs=self._site(li, s2))
+        L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
+        self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g1"])
+        self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID))
+        self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g2"])
+        self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID))
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
@@ -416,16 +392,14 @@ class DiTEngine:
                    pos_offset=N - nc, table=p["rope"], layout=self.rope_layout)
         # -- hoisted layer-0 text / frames blocks
         ly = W.layers[0]
-        p["rss_all"].zero_()
-        self._side_block(ly, "t", 0, p["t0"], p["tL0"], Bt, Dt)
-        self._side_block(ly, "f", 0, p["f0"], p["fL0"], Bt, Df)
+        self._side_block(ly, "t", p["t0"], p["tL0"], Bt, Dt)
+        self._side_block(ly, "f", p["f0"], p["fL0"], Bt, Df)
 
     # ------------------------------------------------------------------------------ forward
     def embed(self, y):
         """x0 = [registers ; proj_in(y) + abs_pos_emb]  (x3:2027, 957-960, 975-976) into xA."""
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, T, N, D = p["B"], p["Bt"], p["T"], p["N"], c.dim
-        p["rss_all"].zero_()            # every norm site of this evaluation accumulates from zero (one memset node)
         L.linear_small(y, W.pin_wt, W.pin_b, W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
                        out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0),
                        regs=W.regs, out_bf16=self._sh(p["xA"]))
@@ -501,7 +475,7 @@ class DiTEngine:
                            epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt)
                     eXt = rec(st)
                     wait(st, eX)                                   # main has read this layer's text buffer
-                    self._side_block(nxt, "t", i + 1, tbuf[0], tbuf[1], Bt, Dt)
+                    self._side_block(nxt, "t", tbuf[0], tbuf[1], Bt, Dt)
                     eT = rec(st)
                 with _On(sf):
                     wait(sf, eA)
@@ -509,7 +483,7 @@ class DiTEngine:
                            epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df)
                     eXf = rec(sf)
                     wait(sf, eX)
-                    self._side_block(nxt, "f", i + 1, fbuf[0], fbuf[1], Bt, Df)
+                    self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df)
                     eF = rec(sf)
                 tc_, fc_ = tbuf[1], fbuf[1]
             # main may overwrite x (and its shadow) only after the side cross GEMMs have read it
@@ -523,33 +497,22 @@ class DiTEngine:
                 L.gemm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], xc,
                        M=rows, N=D, compute=self.cdc, ldo=D)
                 src, dst = xc, xo
-            # audio stream (x3:1121-1137); the three AdaptiveRMSNorms are fused into their producers:
-            #   norm1 <- conv, norm2 (cross-attn, cond rows) and norm3 (ff, null rows) <- self-attn out-projection,
-            #   norm3 (cond rows) <- cross-attn out-projection
+            # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
-            hn = p["hn_a"]
-            g1 = self._g_ada(i, 0)
-            L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens, norm_out=hn, gamma=g1["gamma"],
-                     step=g1["step"], gamma_step_stride=g1["step_stride"], gamma_batch_stride=g1["batch_stride"],
-                     rss_out=self._site(i, 0))
+            L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
             x = dst
-            r2 = nctx * N
-            if nctx > 0:
-                nkw = self._norm_kw(hn, D, self._g_ada(i, 1), self._site(i, 1), self._g_ada(i, 2), self._site(i, 2), r2)
-            else:
-                nkw = self._norm_kw(hn, D, self._g_ada(i, 2), self._site(i, 2))
-            okw = dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0))
-            okw.update(nkw)
-            self._self_attn(ly["a_attn"], x, "a", Bt, D, okw, rs=self._site(i, 0))
+            self._norm_ada(x, p["hn_a"], rows, D, i, 0)
+            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0)))
             if nctx > 0:
                 A2 = ly["a_attn2"]
+                r2 = nctx * N
+                self._norm_ada(x, p["hn_a"], r2, D, i, 1)
                 q2 = p["q2"]
-                nk = dict(rowscale_rss=self._site(i, 1), rowscale_dim=D)
                 if self.rope_cross and self._fuse_rope:
-                    L.gemm([(hn, D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad,
-                           rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **nk)
+                    L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad,
+                           rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N)
                 else:
-                    L.gemm([(hn, D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad, **nk)
+                    L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad)
                     if self.rope_cross:
                         L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
                                table=p["rope"], layout=self.rope_layout)
@@ -562,19 +525,17 @@ class DiTEngine:
                             B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
                             q_len=lens if self.zero_masked_queries else None,
                             scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.cdc)
-                o2 = dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
-                o2.update(self._norm_kw(hn, D, self._g_ada(i, 2), self._site(i, 2)))
-                L.gemm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, compute=self.cdc, resid=x, ldo=D, ldr=D, **o2)
-            fkw = dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2))
-            if last:              # the final RMSNorm (x3:1143) rides on the last feed-forward's epilogue
-                fkw.update(self._norm_kw(hn, D, self._g_plain(W.final_g), self._site(c.depth, 0)))
-            self._ff(ly["a_ff"], x, "a", Bt, D, fkw, rs=self._site(i, 2))
+                L.gemm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, compute=self.cdc, resid=x, ldo=D, ldr=D,
+                       epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
+            self._norm_ada(x, p["hn_a"], rows, D, i, 2)
+            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2)))
             eA = rec(main)
             if i >= half:
                 xc, xo = xo, xc
-        # to_pred on the final-norm operand of all rows (registers are dropped by the consumer) (x3:1141-1143, 2083)
+        # final norm over all rows (registers are dropped by the consumer) + to_pred (x3:1141-1143, 2083)
+        L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g)
         L.gemm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, compute=self.cdc, bias=W.pred_b,
-               ldo=c.num_channels, rowscale_rss=self._site(c.depth, 0), rowscale_dim=D)
+               ldo=c.num_channels)
         return p["pred"]
 
     def euler_step(self, y, cfg_strength: float, remove_parallel_component: bool = False, keep_parallel_frac: float = 0.0):
