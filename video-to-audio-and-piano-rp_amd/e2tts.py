@@ -346,11 +346,17 @@ class E2TTS:
         if text_embed is None:
             if video_paths is not None and self.video_encoder_fn is not None:
                 text_embed = self.video_encoder_fn(video_paths, cond_seq_len)
+            elif video_paths is not None:
+                # cached CLIP features next to the videos, resampled to the latent rate (encode_video's cache branch,
+                # x3:1796-1813); the CLIP encoder itself is outside the accelerated path
+                from .features import encode_video_cached
+                text_embed = encode_video_cached(video_paths, cond_seq_len, dim=cfgm.dim_text, video_encoder=self.video_encoder,
+                                                 sampling_rate=self.sampling_rate or 24000, frame_size=self.frame_size)
             elif torch.is_tensor(text) and text.ndim == 3:
                 text_embed = text
             else:
-                raise NotImplementedError("CLIP encode_video is outside the accelerated path (SURVEY 8f N3): pass "
-                                          "text_embed= (b, n, dim_text) or video_encoder_fn=")
+                raise NotImplementedError("pass video_paths (with cached .npz CLIP features), text_embed= (b, n, dim_text) "
+                                          "or video_encoder_fn=")
         # -- duration (x3:2196-2216)
         if duration is None:
             duration = lens.clone()
