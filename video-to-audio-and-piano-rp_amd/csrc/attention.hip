@@ -124,11 +124,6 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
 // ds_read_b128 A fragments); V tiles are transposed on the way in to [d][68] (136-B rows: 8-B
 // aligned, conflict-free ds_read_b64 of 4 consecutive keys).  2-deep LDS ring, register prefetch.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tanh_fast(float x) {
-  // 1 - 2/(e^{2x}+1): saturates correctly at +-inf of the exponential
-  const float e = __expf(2.0f * x);
-  return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
-}
 
 // NG = 1: 4 waves.  NG = 2: 8 waves, wave group g takes KV tiles g, g+2, ... of the same 64 queries (own LDS
 // ring, shared barrier) and the two partial (m, l, O) states are merged through LDS at the end: twice the
@@ -161,7 +156,10 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f;
-  const float sc = p.clamp > 0.f ? p.scale / p.clamp : p.scale;
+  constexpr float LOG2E = 1.4426950408889634f;
+  // zc: raw QK^T -> argument of the base-2 exponential (2x*log2e with x = scale*s/clamp), or -> log2 units w/o clamp
+  const float zc = p.clamp > 0.f ? 2.0f * LOG2E * p.scale / p.clamp : p.scale * LOG2E;
+  const float c2 = p.clamp * LOG2E;
 
   // staging registers: K rows (tid>>3)+32i chunk tid&7; V key pair kp = lane&31, d-chunk = 2*wave + (lane>>5).
   // Two register sets: tile jt+2 is requested while tile jt is computed and tile jt+1 (requested one
@@ -229,24 +227,39 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
       }
     }
-    // ---- soft clamp, key mask, online softmax (query on the lane)
+    // ---- soft clamp, key mask, online softmax (query on the lane), all in base-2 units:
+    //   clamp*tanh(x)*log2e = C - 2C / (2^(2x log2e) + 1),  C = clamp*log2e   -> v_exp, v_rcp, 1 fma
+    //   p = 2^(t - m)                                                          -> 1 sub, v_exp
     const int j0 = (jt * NG + grp) * TK;
-    const bool partial = j0 + TK > kvn;
     float tmax = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v = s[t][j] * sc;
-        if (p.clamp > 0.f) v = tanh_fast(v) * p.clamp;
-        if (partial && j0 + 16 * t + 4 * g + j >= kvn) v = -INFINITY;   // only the last tile can be partial
+        float v;
+        if (p.clamp > 0.f) {
+          const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
+          v = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2);
+        } else {
+          v = s[t][j] * zc;
+        }
         s[t][j] = v;
-        tmax = fmaxf(tmax, v);
       }
+    if (j0 + TK > kvn) {             // only the last tile can be partial (wave-uniform branch)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j0 + 16 * t + 4 * g + j >= kvn) s[t][j] = -INFINITY;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tmax = fmaxf(tmax, s[t][j]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float mn = fmaxf(m, tmax);
-    const float alpha = __expf(m - mn);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
     m = mn;
     l *= alpha;
 #pragma unroll
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float pv = __expf(s[t][j] - mn);
+        const float pv = __builtin_amdgcn_exp2f(s[t][j] - mn);
         l += pv;
         pf[t >> 1][(t & 1) * 4 + j] = (bf16_t)pv;
       }
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
     const float* src = xch + tid;
     const float m2 = src[0], l2 = src[256];
     const float mn = fmaxf(m, m2);
-    const float a1 = __expf(m - mn), a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+    const float a1 = __builtin_amdgcn_exp2f(m - mn), a2 = (m2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
     l = l * a1 + l2 * a2;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
