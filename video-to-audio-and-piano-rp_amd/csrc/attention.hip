@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
 // NG = 1: 4 waves.  NG = 2: 8 waves, wave group g takes KV tiles g, g+2, ... of the same 64 queries (own LDS
 // ring, shared barrier) and the two partial (m, l, O) states are merged through LDS at the end: twice the
 // waves per SIMD to overlap the softmax VALU work of one wave with the MFMAs / loads of another.
-template <int NG>
+template <int NG, bool CLAMP>
 __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   constexpr int TK = 64, VLD = 68;
   constexpr int K_ELEMS = TK * 64, V_ELEMS = 64 * VLD;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v;
-        if (p.clamp > 0.f) {
+        if constexpr (CLAMP) {
           const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
           v = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2);
         } else {
@@ -366,10 +366,15 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
                          a->q_row_stride % 8 == 0 && a->k_row_stride % 8 == 0 && a->v_row_stride % 8 == 0 &&
                          a->q_batch_stride % 8 == 0 && a->k_batch_stride % 8 == 0 && a->v_batch_stride % 8 == 0 &&
                          a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
-    if (aligned && a->Nk > 128)
-      hipLaunchKernelGGL(attn_mfma_kernel<2>, dim3((a->Nq + 63) / 64, a->H, a->B), dim3(512), 0, s, p);
-    else if (aligned)
-      hipLaunchKernelGGL(attn_mfma_kernel<1>, dim3((a->Nq + 63) / 64, a->H, a->B), dim3(256), 0, s, p);
+    const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
+    const bool cl = a->softclamp > 0.f;
+    if (aligned && a->Nk > 128) {
+      if (cl) hipLaunchKernelGGL((attn_mfma_kernel<2, true>), g64, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((attn_mfma_kernel<2, false>), g64, dim3(512), 0, s, p);
+    } else if (aligned) {
+      if (cl) hipLaunchKernelGGL((attn_mfma_kernel<1, true>), g64, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_mfma_kernel<1, false>), g64, dim3(256), 0, s, p);
+    }
     else
       hipLaunchKernelGGL((attn_rowlane_kernel<bf16_t>), grid, block, 0, s, p);
   }

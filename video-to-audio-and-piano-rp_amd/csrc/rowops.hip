@@ -258,7 +258,7 @@ __global__ void fill_registers_kernel(float* __restrict__ out, int64_t obs, cons
   out[b * obs + r] = regs[r];
 }
 
-// time conditioning: one block per grid point
+// time conditioning: grid = (grid points, column blocks of 256); wt rows are read coalesced, 8 k in flight
 __global__ __launch_bounds__(256) void time_cond_kernel(const float* __restrict__ t, const float* __restrict__ fw,
                                                         const float* __restrict__ wt, const float* __restrict__ bias,
                                                         float* __restrict__ out, int d) {
@@ -274,11 +274,12 @@ __global__ __launch_bounds__(256) void time_cond_kernel(const float* __restrict_
     e[1 + half + i] = cosf(f);
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < d; n += blockDim.x) {
-    float acc = bias[n];
-    for (int k = 0; k < d + 1; ++k) acc += e[k] * wt[(int64_t)k * d + n];
-    out[(int64_t)s * d + n] = silu_f(acc);
-  }
+  const int n = blockIdx.y * blockDim.x + threadIdx.x;
+  if (n >= d) return;
+  float acc = bias[n];
+#pragma unroll 8
+  for (int k = 0; k < d + 1; ++k) acc += e[k] * wt[(int64_t)k * d + n];
+  out[(int64_t)s * d + n] = silu_f(acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -390,7 +391,7 @@ extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float*
   V2A_REQUIRE(x != out, "v2a_dwconv: out must not alias x (halo reads)");
   V2A_REQUIRE(ksize == 31, "v2a_dwconv: kernel_size %d (only 31 is built, x3:726)", ksize);
   V2A_REQUIRE(d % 4 == 0 && B > 0 && N > 0, "v2a_dwconv: B=%d N=%d d=%d", B, N, d);
-  constexpr int TN = 4;
+  constexpr int TN = 8;
   const int c4 = d / 4;
   const int bx = 64;   // one wave = 256 channels: 4x more workgroups than 256-thread blocks (the kernel is latency-bound)
   // grid.y is padded to a multiple of 8 so every XCD label owns a whole range (surplus blocks exit at once)
@@ -446,8 +447,8 @@ extern "C" int v2a_time_cond(const float* t, int32_t S, const float* fw, const f
                              int32_t d, v2a_stream_t stream) {
   V2A_REQUIRE(t && fw && wt && bias && out, "v2a_time_cond: null pointer");
   V2A_REQUIRE(S > 0 && d > 0 && d % 2 == 0, "v2a_time_cond: S=%d d=%d", S, d);
-  hipLaunchKernelGGL(time_cond_kernel, dim3(S), dim3(256), (d + 1) * sizeof(float), (hipStream_t)stream, t, fw, wt, bias,
-                     out, d);
+  hipLaunchKernelGGL(time_cond_kernel, dim3(S, (d + 255) / 256), dim3(256), (d + 1) * sizeof(float), (hipStream_t)stream, t, fw,
+                     wt, bias, out, d);
   return v2a_check_launch("v2a_time_cond");
 }
 
