@@ -159,6 +159,52 @@ def test_gemm_store(L, M, N, K, mode):
         torch.testing.assert_close(out2.cpu().double(), ref, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1564, 2048, 192, "store"), (1564, 10240, 192, "geglu"), (4200, 1024, 320, "resid"),
+                                       (1564, 5120, 128, "gate_resid"), (3300, 2304, 64, "store")])
+def test_gemm_big_tile_persistent_configs(L, M, N, K, epi):
+    """Shapes that select the 128x256 (8-wave) and 128x128 tiles of the persistent LDS-DMA kernel, including more
+    tiles than workgroups (the ring then streams across tile boundaries) and every fused epilogue."""
+    g = _g(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = 0.1 * torch.randn(N, generator=g)
+    acc = a.float().double() @ w.float().double().t()
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    if epi == "store":
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        L.gemm([(ad, K, K)], wd, out, M=M, N=N, compute=L.BF16, bias=bd)
+        torch.testing.assert_close(out.float().cpu().double(), acc + bias.double(), atol=2e-2, rtol=2e-2)
+    elif epi == "geglu":
+        # value / gate rows are taken in the packed [16 | 16] order
+        h = (acc + bias.double()).reshape(M, N // 32, 2, 16)
+        ref = (h[:, :, 0] * torch.nn.functional.gelu(h[:, :, 1])).reshape(M, N // 2)
+        out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
+        L.gemm([(ad, K, K)], wd, out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_GEGLU, bias=bd, ldo=N // 2)
+        torch.testing.assert_close(out.float().cpu().double(), ref, atol=2e-2, rtol=2e-2)
+    elif epi == "resid":
+        # two K segments (192 + 128) as in the U-Net skip GEMM, fp32 out + bf16 shadow
+        a2 = torch.randn(M, 128, generator=g).bfloat16()
+        w2 = (torch.randn(N, 128, generator=g) / math.sqrt(K)).bfloat16()
+        wcat = torch.cat([w, w2], 1).contiguous()
+        resid = torch.randn(M, N, generator=g)
+        ref = resid.double() + acc + a2.float().double() @ w2.float().double().t() + bias.double()
+        out = torch.empty(M, N, device=DEV)
+        sh = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        L.gemm([(ad, K, K), (a2.to(DEV), 128, 128)], wcat.to(DEV), out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID,
+               bias=bd, resid=resid.to(DEV), out_bf16=sh)
+        torch.testing.assert_close(out.cpu().double(), ref, atol=2e-4, rtol=1e-4)
+        assert torch.equal(sh.cpu(), out.cpu().bfloat16())
+    else:
+        resid = torch.randn(M, N, generator=g)
+        gate = torch.rand(2, N, generator=g)
+        step = torch.tensor([1], dtype=torch.int32, device=DEV)
+        ref = resid.double() + gate[1].double() * (acc + bias.double())
+        out = resid.to(DEV)
+        L.gemm([(ad, K, K)], wd, out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_GATE_RESID, bias=bd, resid=out,
+               gate=gate.to(DEV), step=step, gate_step_stride=N, rows_per_batch=782)
+        torch.testing.assert_close(out.cpu().double(), ref, atol=2e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_gemm_three_segments_resid(L, mode):
     """concat-free TextAudioCrossCondition: W [N][Ka+Kb+Kc] against three fp32 row-major streams."""

@@ -166,103 +166,105 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // dead by then), and reads it back row-major 4 columns per lane: bias / GELU / gate / residual run
 // on float4s and every global access is a 16-byte (fp32) or 8-byte (bf16) piece of a contiguous row.
 template <int EPI, typename OutT, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[TM][TN], float* tile /* wave-private */,
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[TM][TN], float* tile /* wave-private, 16 x (WN+4) floats */,
                                                   int m_base, int n_base, int lane) {
   constexpr int LD = WN + 4;                   // 16-B aligned rows, <= 2-way write conflicts
   const int lr = lane & 15, lq = lane >> 4;
+  OutT* out = reinterpret_cast<OutT*>(p.out);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    // one 16-row slab of the wave tile at a time: the staging area of a workgroup is a few KB of one ring stage
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) tile[(i * 16 + lq * 4 + jj) * LD + j * 16 + lr] = acc[i][j][jj];
-  // same wave wrote and reads: LDS operations of one wave complete in order, no barrier needed
-  OutT* out = reinterpret_cast<OutT*>(p.out);
-  if constexpr (EPI == V2A_EPI_GEGLU) {
-    constexpr int OC = WN / 2;                 // output columns of this wave
-    constexpr int LPR = OC / 4;                // lanes per row
-    constexpr int RPI = 64 / LPR;              // rows per pass
-    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-    const int lc = (c4 >> 4) * 32 + (c4 & 15); // LDS column of the value; gate is 16 further
-    const int n = n_base + lc;                 // packed W row of the value
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n < p.N) {
-      bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-      bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
-    }
-#pragma unroll
-    for (int r = r0; r < WM; r += RPI) {
-      const int m = m_base + r;
-      if (m >= p.M || n >= p.N) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
-      OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
-      if constexpr (sizeof(OutT) == 2) {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[e] + bv[e]) * gelu_fast_f(g[e] + bg[e]));
-        *reinterpret_cast<bf16x4*>(dst) = o;
-      } else {
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[e] + bv[e]) * gelu_erf_f(g[e] + bg[e]);
-        *reinterpret_cast<f32x4*>(dst) = o;
+      for (int jj = 0; jj < 4; ++jj) tile[(lq * 4 + jj) * LD + j * 16 + lr] = acc[i][j][jj];
+    // same wave wrote and reads: LDS operations of one wave complete in order, no barrier needed
+    if constexpr (EPI == V2A_EPI_GEGLU) {
+      constexpr int OC = WN / 2;                 // output columns of this wave
+      constexpr int LPR = OC / 4;                // lanes per row
+      constexpr int RPI = 64 / LPR;              // rows per pass
+      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+      const int lc = (c4 >> 4) * 32 + (c4 & 15); // LDS column of the value; gate is 16 further
+      const int n = n_base + lc;                 // packed W row of the value
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) {
+        bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
       }
-    }
-  } else {
-    constexpr int LPR = WN / 4;
-    constexpr int RPI = 64 / LPR;
-    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-    const int n = n_base + c4;
-    const bool full = n + 3 < p.N;             // N is a multiple of 4 for every vector-eligible call (checked on the host)
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && full) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-    for (int r = r0; r < WM; r += RPI) {
-      const int m = m_base + r;
-      if (m >= p.M || !full) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
+      for (int r = r0; r < 16; r += RPI) {
+        const int m = m_base + i * 16 + r;
+        if (m >= p.M || n >= p.N) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
+        OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
+        if constexpr (sizeof(OutT) == 2) {
+          bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bv[e];
-      if constexpr (EPI == V2A_EPI_SIGMOID) {
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[e] + bv[e]) * gelu_fast_f(g[e] + bg[e]));
+          *reinterpret_cast<bf16x4*>(dst) = o;
+        } else {
+          f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
-      }
-      if constexpr (EPI == V2A_EPI_STORE) {
-        if (p.rope && n < p.rope_cols) {
-          // interleaved RoPE (A6): columns (n, n+1) and (n+2, n+3) are pairs (n & 63) / 2 and +1 of this head
-          const int pos = p.rope_pos_off + m % p.rpb;
-          const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)pos * 32 + ((n & 63) >> 1)) * 2);
-          const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
-          v[0] = a0 * cs[0] - b0 * cs[1];
-          v[1] = b0 * cs[0] + a0 * cs[1];
-          v[2] = a1 * cs[2] - b1 * cs[3];
-          v[3] = b1 * cs[2] + a1 * cs[3];
+          for (int e = 0; e < 4; ++e) o[e] = (v[e] + bv[e]) * gelu_erf_f(g[e] + bg[e]);
+          *reinterpret_cast<f32x4*>(dst) = o;
         }
       }
-      if constexpr (EPI == V2A_EPI_RESID) {
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+    } else {
+      constexpr int LPR = WN / 4;
+      constexpr int RPI = 64 / LPR;
+      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+      const int n = n_base + c4;
+      const bool full = n + 3 < p.N;             // N is a multiple of 4 for every vector-eligible call (checked on the host)
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && full) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += rs[e];
-      }
-      if constexpr (EPI == V2A_EPI_GATE_RESID) {
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
-        const f32x4 gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+      for (int r = r0; r < 16; r += RPI) {
+        const int m = m_base + i * 16 + r;
+        if (m >= p.M || !full) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
-      }
-      if constexpr (sizeof(OutT) == 2) {
-        bf16x4 o;
+        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        if constexpr (EPI == V2A_EPI_SIGMOID) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-        *reinterpret_cast<bf16x4*>(out + (int64_t)m * p.ldo + n) = o;
-      } else {
-        *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldo + n) = v;
-        if (p.out2) {
+          for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+        }
+        if constexpr (EPI == V2A_EPI_STORE) {
+          if (p.rope && n < p.rope_cols) {
+            // interleaved RoPE (A6): columns (n, n+1) and (n+2, n+3) are pairs (n & 63) / 2 and +1 of this head
+            const int pos = p.rope_pos_off + m % p.rpb;
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)pos * 32 + ((n & 63) >> 1)) * 2);
+            const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+            v[0] = a0 * cs[0] - b0 * cs[1];
+            v[1] = b0 * cs[0] + a0 * cs[1];
+            v[2] = a1 * cs[2] - b1 * cs[3];
+            v[3] = b1 * cs[2] + a1 * cs[3];
+          }
+        }
+        if constexpr (EPI == V2A_EPI_RESID) {
+          const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rs[e];
+        }
+        if constexpr (EPI == V2A_EPI_GATE_RESID) {
+          const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+          const f32x4 gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
+        }
+        if constexpr (sizeof(OutT) == 2) {
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x4*>(p.out2 + (int64_t)m * p.ldo2 + n) = o;
+          *reinterpret_cast<bf16x4*>(out + (int64_t)m * p.ldo + n) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldo + n) = v;
+          if (p.out2) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x4*>(p.out2 + (int64_t)m * p.ldo2 + n) = o;
+          }
         }
       }
     }
@@ -563,8 +565,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   if (p.vec_epi) {
     __builtin_amdgcn_s_barrier();   // every wave is done reading the K-loop stages; all DMAs were retired above
-    static_assert(NW * WM * (WN + 4) * 4 <= 3 * STAGE_BYTES, "epilogue tiles must fit in the stage memory");
-    float* tile = reinterpret_cast<float*>(smem_raw) + wave * (WM * (WN + 4));
+    static_assert(NW * 16 * (WN + 4) * 4 <= STAGE_BYTES, "epilogue slabs must fit in one ring stage");
+    float* tile = reinterpret_cast<float*>(smem_raw) + wave * (16 * (WN + 4));
     gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane);
   } else {
     gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
