@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="print a per-GEMM-shape timing table to stderr")
+    ap.add_argument("--no-batched", action="store_true", help="skip the supplementary 8-clips-per-GPU measurement (N=1 only)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="grid points of the bounded CPU sample")
     args = ap.parse_args()
 
@@ -161,7 +162,11 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        if not args.no_batched and B == 1:
+            res["batched"] = batched_leg(model, cfg, cfm_steps, args, T, NC, dev)
+            log("batched leg done")
         if not args.no_roofline:
+            one_step()                                     # restore the B=1 plan (and its graph) after the batched leg
             res["roofline"] = roofline_leg(model, L, y0, args)
             log("roofline leg done")
         if not args.no_cpu_baseline:
@@ -171,6 +176,30 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def batched_leg(model, cfg, cfm_steps, args, T, NC, dev):
+    """Supplementary: the same sampler with 8 clips per GPU (the per-GPU shape of BASELINE.json configs[2]); the GEMMs
+    then see M = 12512 rows instead of 1564.  Not the headline `value`."""
+    from v2a_amd.synth import synthetic_conditioning
+    Bb = 8
+    y0, text, roll, ctx, cm = synthetic_conditioning(cfg, Bb, T, NC, seed=77, piano=args.v2p, device=dev)
+    cond = torch.empty(Bb, T, cfg.num_channels, device=dev)
+    lens = torch.full((Bb,), T, dtype=torch.long)
+    def run():
+        return model.sample(cond, y0=y0, text_embed=text, context=ctx, context_mask=cm.cpu(), frames_embed=roll, lens=lens, duration=lens,
+                            steps=cfm_steps, cfg_strength=args.cfg_strength, remove_parallel_component=False, sway_sampling=True,
+                            return_raw_output=True)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        out = run()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / n
+    assert bool(torch.isfinite(out).all())
+    return {"clips_per_gpu": Bb, "mel_frames_per_s": round(Bb * T / el, 2), "ms_per_step": round(el * 1e3, 2), "clips_per_s": round(Bb / el, 3)}
 
 
 def roofline_leg(model, L, y0, args):
