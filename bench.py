@@ -203,15 +203,17 @@ def batched_leg(model, cfg, cfm_steps, args, T, NC, dev):
 
 
 def roofline_leg(model, L, y0, args):
-    """Eager replay of Euler evaluations with every launch bracketed by HIP events on the launch
-    stream.  `achieved` = algorithmic FLOPs (2*M*N*K per launch) / event-measured kernel time for the
-    GEMM instantiation that takes the most time in a step; the per-kernel table is attached."""
+    """Eager replay of Euler evaluations on ONE stream with every launch bracketed by HIP events recorded on the
+    launch stream (GEMMs: 8 back-to-back launches per event pair, which amortises the ~5 us dispatch gap an eager
+    event pair includes, so avg_launch_us agrees with rocprofv3's kernel durations in profiles/).  `achieved` =
+    algorithmic FLOPs (2*M*N*K per launch) / that time for the GEMM instantiation with the most time per
+    evaluation; the per-kernel table is attached."""
     eng = model.engine()
     p = eng.plan
     y = p["y"]
     reps = 3
     side = (p.pop("st", None), p.pop("sf", None))     # kernels one at a time: isolated launch durations
-    prof = L.KernelProfiler()
+    prof = L.KernelProfiler(inner=8)
     keep = y.clone()
     # warm: one untimed eager evaluation
     p["step"].zero_()
@@ -225,7 +227,7 @@ def roofline_leg(model, L, y0, args):
         L.set_profiler(None)
     agg = prof.summary()
     if args.shapes:       # per-shape GEMM table on stderr (tuning aid)
-        prof2 = L.KernelProfiler(shapes=True)
+        prof2 = L.KernelProfiler(shapes=True, inner=8)
         L.set_profiler(prof2)
         try:
             for _ in range(reps):

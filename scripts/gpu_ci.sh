@@ -36,7 +36,7 @@ for s in "$@"; do
              TAILN=0 run dbg_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --shapes
              echo "--- dbg $t"; grep -E "timed|gemm<" gpurun_out/dbg_$t.log | sed -E 's/\[bench [0-9.]+s\] //' | sort | head -40
            done; unset V2A_GEMM_DBG ;;
-    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph"
+    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph --no-batched"
          i=0
          for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
            i=$((i+1)); rm -rf /tmp/pmc$i
@@ -45,7 +45,7 @@ for s in "$@"; do
          done ;;
     small) for t in 3 2 1 0; do
              export V2A_GEMM_SMALL=$t
-             TAILN=0 run small_$t 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
+             TAILN=0 run small_$t 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched
              echo "--- small cfg $t: $(grep -E 'timed' gpurun_out/small_$t.log)"
            done; unset V2A_GEMM_SMALL ;;
     bench2) V2A_BENCH_BACKEND=gloo run bench2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 ;;
@@ -66,9 +66,9 @@ for s in "$@"; do
              TAILN=0 run prio8_$t 300 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --clips-per-gpu 8
              echo "--- prio $t B=8: $(grep -E 'timed' gpurun_out/prio8_$t.log)"
            done; unset V2A_GEMM_DBG ;;
-    prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline
+    prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched
           mkdir -p gpurun_out/prof; cp /tmp/prof/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_multistream.csv ;;
-    prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream
+    prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched
           mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
     *) echo "unknown step $s" ;;
   esac
