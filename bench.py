@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--frames", type=int, default=750)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--v2p", action="store_true", help="configs[3]: non-zero piano roll, 64 steps")
+    ap.add_argument("--cascade", type=int, default=1, help="configs[4]: this many sequential sample() passes per step (the "
+                    "reference has no CoT-guidance code, SURVEY 8d: defined here as cascaded 32-step passes, each pass "
+                    "starting from fresh noise with the same conditioning)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="no side streams: kernels run one at a time (profiling aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,9 +118,10 @@ def main():
     n_clips = B * world
 
     def one_step(steps=cfm_steps):
-        out = model.sample(cond, y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, lens=lens,
-                           duration=lens, steps=steps, cfg_strength=args.cfg_strength, remove_parallel_component=False,
-                           sway_sampling=True, return_raw_output=True)
+        for _ in range(args.cascade):
+            out = model.sample(cond, y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, lens=lens,
+                               duration=lens, steps=steps, cfg_strength=args.cfg_strength, remove_parallel_component=False,
+                               sway_sampling=True, return_raw_output=True)
         return v2a_amd.gather_latents(out, n_clips, B)
 
     log("model ready: %s, B=%d/GPU, %d-point grid" % (args.dtype, B, cfm_steps))
@@ -143,7 +147,7 @@ def main():
     log("timed %d steps: %.1f ms/step" % (args.steps, el / args.steps * 1e3))
 
     ms_per_step = el / args.steps * 1e3
-    frames_per_s = n_clips * T / (el / args.steps)
+    frames_per_s = n_clips * T * args.cascade / (el / args.steps)
     evals = cfm_steps - 1
     # algorithmic work per forward per clip at this shape (1040.7 GFLOP GEMM + 75.8 attention)
     res = {
@@ -155,7 +159,7 @@ def main():
                                "evaluations (%d DiT forwards), T5 context %d tokens, %s"
                                % (3 if args.v2p else 1, B, T, cfm_steps, evals, 2 * evals, NC, "V2P roll" if args.v2p else "V2A zero roll"),
                    "clips_per_gpu": B, "global_clips": n_clips, "parallelism": "clip-sharded x%d, 1 all-gather" % world,
-                   "hipgraph": not args.no_graph, "side_streams": not args.single_stream},
+                   "hipgraph": not args.no_graph, "side_streams": not args.single_stream, "cascade_passes": args.cascade},
         "per_gpu_mel_frames_per_s": round(frames_per_s / world, 2),
         "clips_per_s": round(n_clips / (el / args.steps), 4),
         "ms_per_cfg_evaluation": round(ms_per_step / evals, 4),

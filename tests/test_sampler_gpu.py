@@ -181,3 +181,19 @@ def test_cli_end_to_end(tmp_path, small):
     ref = m.sample(batch8[1], lens=batch8[3], duration=batch8[3], steps=4, cfg_strength=2.0, remove_parallel_component=False,
                    video_drop_prompt=batch8[4], return_raw_output=True, y0=None, **extras)
     assert ref.shape[0] == 2 and ref.shape[1] == int(batch8[3].max())
+
+
+def test_plan_switching_and_graph_reuse(small):
+    """sample() with changing batch size / length / step count re-plans (new buffers, new graph) and returning to an
+    earlier shape reproduces the earlier result bit for bit."""
+    i = small["inp"]
+    m = make_model(small["cfg"], small["P"], "bf16")
+    kw = dict(cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)
+    a = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], steps=4, **_kw(i), **kw)
+    one = {k: v[:1, :33] if k in ("y0", "text", "roll") else v[:1] for k, v in i.items()}
+    b = m.sample(torch.zeros(1, 33, 16), y0=one["y0"], steps=6, **_kw(one), **kw)
+    assert b.shape == (1, 33, 16) and bool(torch.isfinite(b).all())
+    c = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], steps=4, **_kw(i), **kw)
+    assert torch.equal(a, c)
+    d = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], steps=7, **_kw(i), **kw)       # same plan key except S
+    assert not torch.equal(a, d)

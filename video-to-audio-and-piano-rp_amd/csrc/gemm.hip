@@ -36,7 +36,6 @@ struct GemmParams {
   const float* rope;     // cos/sin table [pos][32][2] or null: rotate interleaved pairs of columns < rope_cols (STORE epilogue)
   int32_t rope_cols, rope_pos_off;
   int32_t vec_epi;  // all epilogue pointers / strides allow 16-byte row pieces
-  int32_t dbg;   // tuning aid (env V2A_GEMM_DBG): 1 = skip epilogue stores, 2 = skip DMA issue, 4 = skip MFMA
 };
 
 template <typename T> struct TileCfg;
@@ -523,9 +522,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   };
 
   const int nk = p.K / 64;
-  const bool do_dma = !(p.dbg & 2);
-  if (do_dma) issue(0, 0);
-  if (nk > 1 && do_dma) issue(1, 1);
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
   // one K tile; STAGE is a compile-time ring position so every LDS address is base + immediate
   auto tile = [&](auto stage_c, int kt) {
     constexpr int STAGE = decltype(stage_c)::value;
@@ -533,8 +531,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1)%3
-    if (kt + 2 < nk && do_dma) issue(kt + 2, (STAGE + 2) % 3);
-    if (p.dbg & 4) return;
+    if (kt + 2 < nk) issue(kt + 2, (STAGE + 2) % 3);
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
     const bf16_t* Ws = As + BM * 64;
 #pragma unroll
@@ -562,7 +559,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     if (kt + 1 < nk) tile(std::integral_constant<int, 1>{}, kt + 1);
     if (kt + 2 < nk) tile(std::integral_constant<int, 2>{}, kt + 2);
   }
-  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   if (p.vec_epi) {
     __builtin_amdgcn_s_barrier();   // every wave is done reading the K-loop stages; all DMAs were retired above
     static_assert(NW * 16 * (WN + 4) * 4 <= STAGE_BYTES, "epilogue slabs must fit in one ring stage");
@@ -671,8 +667,6 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
                     a->rope_cols % 64 == 0 && a->rope_cols <= a->N && ((uintptr_t)a->rope_table & 15) == 0,
                 "v2a_gemm: fused RoPE needs the bf16 STORE epilogue with 16-byte aligned rows and rope_cols %% 64 == 0");
   }
-  static const int dbg = getenv("V2A_GEMM_DBG") ? atoi(getenv("V2A_GEMM_DBG")) : 0;
-  p.dbg = dbg;
   if (a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID)
     V2A_REQUIRE(a->resid != nullptr, "v2a_gemm: epilogue %d needs resid", a->epilogue);
   if (a->epilogue == V2A_EPI_GATE_RESID) V2A_REQUIRE(a->gate != nullptr, "v2a_gemm: GATE_RESID needs gate");
