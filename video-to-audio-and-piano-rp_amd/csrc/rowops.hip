@@ -61,67 +61,89 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // Depthwise conv (k taps along N) + bias + SiLU + mask + residual.
-// A thread owns 4 consecutive channels and TN consecutive positions; it streams the
-// TN + k - 1 input rows once (float4 each) and scatters every input into the <= k outputs
-// that use it; the k tap weights (float4 each, [k][d] layout -> coalesced) stay in registers.
+// Block = 4 waves = 4 consecutive position tiles of TN outputs for the same 256 channels (a lane owns 4 channels).
+// The k x 256 tap weights are fetched ONCE per block into LDS (8 float4 per thread instead of 31 per wave); every
+// thread then issues all TN + k - 1 input rows it needs back to back (one memory latency instead of one per row)
+// and sweeps the taps with the weights read from LDS.  Algorithmic traffic: 4*d B in + 4*d B out per position.
 // ------------------------------------------------------------------------------------------
 template <int KS, int TN>
-__global__ __launch_bounds__(64) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                      const float* __restrict__ wt, const float* __restrict__ bias,
                                                      int B, int N, int d, const int32_t* len) {
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so flat id % 8 labels the L2 a
-  // block will use.  Give each label a contiguous range of position tiles (all channel blocks of a tile
-  // together): the k-1 halo rows a tile shares with its neighbours then hit in that XCD's L2 instead of
-  // being fetched over the fabric once per tile (measured 4.7x the algorithmic bytes without this).
+  __shared__ __attribute__((aligned(16))) float wl[KS * 256];
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so flat id % 8 labels the L2 a block will
+  // use.  Give each label a contiguous range of position tiles (all channel blocks of a tile together): the k-1
+  // halo rows a tile shares with its neighbours then hit in that XCD's L2 instead of being fetched over the
+  // fabric once per tile (measured 4.7x the algorithmic bytes without this).
   const int CB = gridDim.x, P = gridDim.y;
   const int flat = blockIdx.y * CB + blockIdx.x;
-  const int per = (P + 7) >> 3;                          // position tiles per XCD label
-  const int xcd = flat & 7, slot = flat >> 3;            // slot in [0, ceil(P*CB/8))
+  const int per = (P + 7) >> 3;                          // position tiles (of 4*TN) per XCD label
+  const int xcd = flat & 7, slot = flat >> 3;
   const int ptile = xcd * per + slot / CB, cblk = slot % CB;
   const int b = blockIdx.z;
-  const int c4 = cblk * blockDim.x + threadIdx.x;        // float4 channel group
-  if (ptile >= P || slot >= per * CB || c4 * 4 >= d) return;
-  const int n0 = ptile * TN;
-  const int L = len ? min(len[b], N) : N;
-  constexpr int HALF = KS / 2;
+  if (ptile >= P || slot >= per * CB) return;            // whole block
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: row tests become scalar
+  const int c4 = cblk * 64 + lane;                       // float4 channel group of this lane
+  const bool cok = c4 * 4 < d;
+  const int cc = cok ? c4 : d / 4 - 1;                   // idle lanes shadow a valid channel group, only the store is masked
+  for (int i = threadIdx.x; i < KS * 64; i += 256) {     // taps x 64 float4 of this channel block, once per block
+    const int tap = i >> 6;
+    int ch4 = cblk * 64 + (i & 63);
+    ch4 = ch4 * 4 < d ? ch4 : d / 4 - 1;
+    *reinterpret_cast<f32x4*>(wl + i * 4) = *reinterpret_cast<const f32x4*>(wt + (int64_t)tap * d + 4 * ch4);
+  }
+  __syncthreads();
   f32x4 w[KS];
 #pragma unroll
-  for (int j = 0; j < KS; ++j) w[j] = *reinterpret_cast<const f32x4*>(wt + (int64_t)j * d + 4 * c4);
+  for (int j = 0; j < KS; ++j) w[j] = *reinterpret_cast<const f32x4*>(wl + (j * 64 + lane) * 4);
+
+  const int n0 = (ptile * 4 + wave) * TN;                // wave-uniform
+  const int L = len ? min(len[b], N) : N;
+  constexpr int HALF = KS / 2;
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * cc);
   f32x4 acc[TN];
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
 #pragma unroll
   for (int t = 0; t < TN; ++t) acc[t] = bv;
-  const float* xb = x + (int64_t)b * N * d + 4 * c4;
-  // input position p = n0 - HALF + i contributes to output t with tap j = p - (n0 + t) + HALF = i - t
+  // row base is wave-uniform (SGPR), the lane contributes a constant 32-bit byte offset: no vector address math
+  const char* xrow0 = reinterpret_cast<const char*>(x + (int64_t)b * N * d);
+  const uint32_t loff = (uint32_t)cc * 16u;
+  f32x4 center[TN];
+  // input position n0 - HALF + i contributes to output t with tap j = i - t.  Straight-line code: every row is
+  // loaded (clamped into the sequence) and scaled by a 0/1 wave-uniform factor instead of being branched around,
+  // so all loads of the tile are in flight together and the FMA stream has no control flow.  (Measured variants:
+  // per-row branches 14.1 us, this form 10.0 us, chunked / register-capped forms spill and are slower.)
 #pragma unroll
   for (int i = 0; i < TN + KS - 1; ++i) {
-    const int pos = n0 - HALF + i;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool valid = pos >= 0 && pos < N;
-    if (valid) v = *reinterpret_cast<const f32x4*>(xb + (int64_t)pos * d);
-    if (!(valid && pos < L)) continue;                      // masked input -> zero contribution
+    const int pos = n0 - HALF + i;                       // wave-uniform
+    const int pc = min(max(pos, 0), N - 1);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)pc * d * 4 + loff);
+    if (i >= HALF && i < HALF + TN) center[i - HALF] = v;   // unmasked x for the residual (x3:1082: conv(x, mask) + x)
+    const float f = (pos >= 0 && pos < L) ? 1.0f : 0.0f;    // zero padding and masked rows contribute nothing
+    const f32x4 vm = {v[0] * f, v[1] * f, v[2] * f, v[3] * f};
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
       const int j = i - t;
       if (j >= 0 && j < KS) {
-        acc[t][0] += w[j][0] * v[0];
-        acc[t][1] += w[j][1] * v[1];
-        acc[t][2] += w[j][2] * v[2];
-        acc[t][3] += w[j][3] * v[3];
+        acc[t][0] += w[j][0] * vm[0];
+        acc[t][1] += w[j][1] * vm[1];
+        acc[t][2] += w[j][2] * vm[2];
+        acc[t][3] += w[j][3] * vm[3];
       }
     }
   }
-  float* ob = out + (int64_t)b * N * d + 4 * c4;
+  if (!cok) return;
+  char* orow0 = reinterpret_cast<char*>(out + (int64_t)b * N * d);
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int n = n0 + t;
     if (n >= N) break;
-    f32x4 o = *reinterpret_cast<const f32x4*>(xb + (int64_t)n * d);  // unmasked x for the residual (L1/L2 hit)
+    f32x4 o = center[t];
     if (n < L) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] += silu_f(acc[t][j]);
     }
-    *reinterpret_cast<f32x4*>(ob + (int64_t)n * d) = o;
+    *reinterpret_cast<f32x4*>(orow0 + (int64_t)n * d * 4 + loff) = o;
   }
 }
 
@@ -392,11 +414,10 @@ extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float*
   V2A_REQUIRE(ksize == 31, "v2a_dwconv: kernel_size %d (only 31 is built, x3:726)", ksize);
   V2A_REQUIRE(d % 4 == 0 && B > 0 && N > 0, "v2a_dwconv: B=%d N=%d d=%d", B, N, d);
   constexpr int TN = 8;
-  const int c4 = d / 4;
-  const int bx = 64;   // one wave = 256 channels: 4x more workgroups than 256-thread blocks (the kernel is latency-bound)
-  // grid.y is padded to a multiple of 8 so every XCD label owns a whole range (surplus blocks exit at once)
-  const int P = (N + TN - 1) / TN;
-  dim3 grid((c4 + bx - 1) / bx, ((P + 7) / 8) * 8, B), block(bx);
+  const int cb = (d / 4 + 63) / 64;                      // 256-channel blocks
+  // grid.y counts groups of 4 position tiles, padded to a multiple of 8 so every XCD label owns a whole range
+  const int P = (N + 4 * TN - 1) / (4 * TN);
+  dim3 grid(cb, ((P + 7) / 8) * 8, B), block(256);
   hipLaunchKernelGGL((dwconv_kernel<31, TN>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
   return v2a_check_launch("v2a_dwconv_silu_residual");
 }
