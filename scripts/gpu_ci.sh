@@ -41,6 +41,11 @@ for s in "$@"; do
     shapes8) run shapes8 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --shapes --single-stream --clips-per-gpu 8 ;;
     configs) TAILN=2 run cfg_v2p 300 python bench.py --steps 2 --warmup 1 --v2p --no-cpu-baseline --no-roofline --no-batched
              TAILN=2 run cfg_cascade 300 python bench.py --steps 2 --warmup 1 --cascade 3 --clips-per-gpu 4 --no-cpu-baseline --no-roofline --no-batched ;;
+    big) for t in 0 1; do
+           export V2A_GEMM_BIG=$t
+           TAILN=0 run big_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --clips-per-gpu 8
+           echo "--- big $t B=8: $(grep -E 'timed' gpurun_out/big_$t.log)"
+         done; unset V2A_GEMM_BIG ;;
     prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched
           mkdir -p gpurun_out/prof; cp /tmp/prof/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_multistream.csv ;;
     prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched

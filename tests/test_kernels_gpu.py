@@ -160,10 +160,11 @@ def test_gemm_store(L, M, N, K, mode):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(1564, 2048, 192, "store"), (1564, 10240, 192, "geglu"), (4200, 1024, 320, "resid"),
-                                       (1564, 5120, 128, "gate_resid"), (3300, 2304, 64, "store")])
+                                       (1564, 5120, 128, "gate_resid"), (3300, 2304, 64, "store"),
+                                       (8200, 4096, 192, "store"), (8200, 4096, 128, "geglu"), (8300, 4096, 64, "gate_resid")])
 def test_gemm_big_tile_persistent_configs(L, M, N, K, epi):
-    """Shapes that select the 128x256 (8-wave) and 128x128 tiles of the persistent LDS-DMA kernel, including more
-    tiles than workgroups (the ring then streams across tile boundaries) and every fused epilogue."""
+    """Shapes that select the 256x256 (2-deep ring), 128x256 (8-wave) and 128x128 tiles of the LDS-DMA kernel, including
+    partial edge tiles, single- and multi-tile K loops and every fused epilogue."""
     g = _g(M + N + K)
     a = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()

@@ -430,7 +430,7 @@ int dispatch_epi(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 // image linear per wave, XOR swizzle applied to the per-lane SOURCE chunk: rule 21 of the CDNA guide),
 // two K tiles stay in flight across the single raw s_barrier of each iteration (counted vmcnt),
 // and no VGPRs or ds_writes are spent on staging.
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int AUXW = 0>
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -515,23 +515,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
       if (g < GA)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + goff[i]),
                                          (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
-      else   // W is streamed: AUXW = 2 marks the loads non-temporal
+      else
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + goff[i]),
-                                         (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, AUXW);
+                                         (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
     }
   };
 
   const int nk = p.K / 64;
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  // ring of NST stages (3: two tiles in flight while one is computed; 2: the 256x256 tile, whose 64 KB stages leave
+  // room for only two)
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) issue(s0, s0);
   // one K tile; STAGE is a compile-time ring position so every LDS address is base + immediate
   auto tile = [&](auto stage_c, int kt) {
     constexpr int STAGE = decltype(stage_c)::value;
-    // tile kt has landed for this wave once at most the younger tile's DMAs remain outstanding
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    // tile kt has landed for this wave once only the younger tile's DMAs remain outstanding
+    if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1)%3
-    if (kt + 2 < nk) issue(kt + 2, (STAGE + 2) % 3);
+    __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1) % NST
+    if (kt + NST - 1 < nk) issue(kt + NST - 1, (STAGE + NST - 1) % NST);
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
     const bf16_t* Ws = As + BM * 64;
 #pragma unroll
@@ -554,14 +557,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   };
-  for (int kt = 0; kt < nk; kt += 3) {
+  for (int kt = 0; kt < nk; kt += NST) {
     tile(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < nk) tile(std::integral_constant<int, 1>{}, kt + 1);
-    if (kt + 2 < nk) tile(std::integral_constant<int, 2>{}, kt + 2);
+    if constexpr (NST == 3) {
+      if (kt + 2 < nk) tile(std::integral_constant<int, 2>{}, kt + 2);
+    }
   }
   if (p.vec_epi) {
     __builtin_amdgcn_s_barrier();   // every wave is done reading the K-loop stages; all DMAs were retired above
-    static_assert(NW * 16 * (WN + 4) * 4 <= STAGE_BYTES, "epilogue slabs must fit in one ring stage");
+    static_assert(NW * 16 * (WN + 4) * 4 <= NST * STAGE_BYTES, "epilogue slabs must fit in the ring memory");
     float* tile = reinterpret_cast<float*>(smem_raw) + wave * (16 * (WN + 4));
     gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane);
   } else {
@@ -569,13 +574,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   }
 }
 
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN>
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST>
 int launch_dma(const GemmParams& p, hipStream_t s) {
-  constexpr size_t smem = 3 * (size_t)(BM + BN) * 128;
+  constexpr size_t smem = NST * (size_t)(BM + BN) * 128;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
-  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, 0>;
+  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -585,20 +590,20 @@ int launch_dma(const GemmParams& p, hipStream_t s) {
   return v2a_check_launch("v2a_gemm(dma)");
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NST = 3>
 int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
   const bool out_f32 = a->out_dtype == V2A_F32;
   switch (a->epilogue) {
     case V2A_EPI_STORE:
-      return out_f32 ? launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN>(p, s) : launch_dma<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN>(p, s);
+      return out_f32 ? launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST>(p, s) : launch_dma<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
     case V2A_EPI_GEGLU:
-      if (!out_f32) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN>(p, s);
+      if (!out_f32) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
       break;
     case V2A_EPI_RESID:
-      if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN>(p, s);
+      if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN, NST>(p, s);
       break;
     case V2A_EPI_GATE_RESID:
-      if (out_f32) return launch_dma<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN>(p, s);
+      if (out_f32) return launch_dma<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST>(p, s);
       break;
   }
   return v2a_fail(V2A_ERR_ARG, "v2a_gemm(dma): unsupported epilogue %d / out_dtype %d", a->epilogue, a->out_dtype);
@@ -679,14 +684,17 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   auto ntiles = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
   static const int force = getenv("V2A_GEMM_TILE") ? atoi(getenv("V2A_GEMM_TILE")) : -1;   // tuning aid
   static const int small = getenv("V2A_GEMM_SMALL") ? atoi(getenv("V2A_GEMM_SMALL")) : -1;
+  static const int big = getenv("V2A_GEMM_BIG") ? atoi(getenv("V2A_GEMM_BIG")) : 1;          // 0: never use the 256x256 tile
   int cfg;
   if (force >= 0) cfg = force;
+  else if (big && ntiles(256, 256) >= 512 && a->N >= 2048) cfg = 5;   // batched clips, wide outputs: halve the fill bytes per flop
   else if ((a->N >= 2048 && ntiles(128, 256) >= 96) || ntiles(128, 256) >= 200) cfg = 0;   // wide outputs, or large M
   else if (small >= 0) cfg = small;                                     // tuning aid: V2A_GEMM_SMALL
   else if (ntiles(128, 128) >= 256) cfg = 1;                            // batched clips, narrow outputs
   else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;
   else cfg = 3;
   switch (cfg) {
+    case 5: return dispatch_dma<256, 256, 2, 4, 2>(a, p, s); // 8 waves, 128x64 wave tiles, 2-deep ring of 64 KB stages
     case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);   // 8 waves, 144 KB LDS, 1 workgroup/CU
     case 1: return dispatch_dma<128, 128, 2, 2>(a, p, s);   // 4 waves,  96 KB
     case 2: return dispatch_dma<128, 64, 2, 2>(a, p, s);    // 4 waves,  72 KB, 2 workgroups/CU
