@@ -164,9 +164,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // Instead every wave parks its WM x WN fp32 tile in a private LDS region (the K-loop stages are
 // dead by then), and reads it back row-major 4 columns per lane: bias / GELU / gate / residual run
 // on float4s and every global access is a 16-byte (fp32) or 8-byte (bf16) piece of a contiguous row.
-template <int EPI, typename OutT, int TM, int TN, int WM, int WN>
+// Residual / gate pieces of the vector epilogue, fetched at kernel start so their L2/HBM latency hides under the K loop
+// instead of being paid once per 16-row slab at the tail of every workgroup (same lane -> (row, 4 columns) map as below).
+template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
+  static constexpr int LPR = WN / 4, RPI = 64 / LPR, RPS = 16 / RPI;   // lanes per row, rows per pass, rows per slab and lane
+  static constexpr bool RES = ON && (EPI == V2A_EPI_RESID || EPI == V2A_EPI_GATE_RESID);
+  static constexpr bool GATE = ON && EPI == V2A_EPI_GATE_RESID;
+  f32x4 rs[RES ? TM : 1][RES ? RPS : 1];
+  f32x4 gt[GATE ? TM : 1][GATE ? RPS : 1];
+  static constexpr bool ROPE = ON && EPI == V2A_EPI_STORE;
+  f32x4 cs[ROPE ? TM : 1][ROPE ? RPS : 1];     // (cos, sin) of the two column pairs a lane rotates
+  __device__ __forceinline__ void load(const GemmParams& p, int m_base, int n_base, int lane) {
+    if constexpr (ROPE) {
+      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+      const int n = n_base + c4;
+      if (p.rope && n < p.rope_cols) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < RPS; ++q) {
+            int m = m_base + i * 16 + r0 + q * RPI;
+            m = m < p.M ? m : p.M - 1;
+            const int pos = p.rope_pos_off + m % p.rpb;
+            cs[i][q] = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)pos * 32 + ((n & 63) >> 1)) * 2);
+          }
+      }
+    }
+    if constexpr (RES) {
+      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+      const int n = n_base + c4;
+      const bool full = n + 3 < p.N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < RPS; ++q) {
+          const int m = m_base + i * 16 + r0 + q * RPI;
+          if (m < p.M && full) {
+            rs[i][q] = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+            if constexpr (GATE) gt[i][q] = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+          }
+        }
+    }
+  }
+};
+
+template <int EPI, typename OutT, int TM, int TN, int WM, int WN, bool PF>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[TM][TN], float* tile /* wave-private, 16 x (WN+4) floats */,
-                                                  int m_base, int n_base, int lane) {
+                                                  int m_base, int n_base, int lane, const EpiPrefetch<EPI, TM, WN, PF>& pf) {
   constexpr int LD = WN + 4;                   // 16-B aligned rows, <= 2-way write conflicts
   const int lr = lane & 15, lq = lane >> 4;
   OutT* out = reinterpret_cast<OutT*>(p.out);
@@ -218,7 +262,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias && full) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-      for (int r = r0; r < 16; r += RPI) {
+      for (int q = 0; q < 16 / RPI; ++q) {
+        const int r = r0 + q * RPI;
         const int m = m_base + i * 16 + r;
         if (m >= p.M || !full) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
@@ -231,8 +276,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         if constexpr (EPI == V2A_EPI_STORE) {
           if (p.rope && n < p.rope_cols) {
             // interleaved RoPE (A6): columns (n, n+1) and (n+2, n+3) are pairs (n & 63) / 2 and +1 of this head
-            const int pos = p.rope_pos_off + m % p.rpb;
-            const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)pos * 32 + ((n & 63) >> 1)) * 2);
+            f32x4 cs;
+            if constexpr (PF) cs = pf.cs[i][q];
+            else cs = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)(p.rope_pos_off + m % p.rpb) * 32 + ((n & 63) >> 1)) * 2);
             const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
             v[0] = a0 * cs[0] - b0 * cs[1];
             v[1] = b0 * cs[0] + a0 * cs[1];
@@ -240,14 +286,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
             v[3] = b1 * cs[2] + a1 * cs[3];
           }
         }
-        if constexpr (EPI == V2A_EPI_RESID) {
-          const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rs[e];
-        }
-        if constexpr (EPI == V2A_EPI_GATE_RESID) {
-          const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
-          const f32x4 gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+        if constexpr (EPI == V2A_EPI_RESID || EPI == V2A_EPI_GATE_RESID) {
+          f32x4 rs, gt = {1.f, 1.f, 1.f, 1.f};
+          if constexpr (PF) {
+            rs = pf.rs[i][q];
+            if constexpr (EPI == V2A_EPI_GATE_RESID) gt = pf.gt[i][q];
+          } else {
+            rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+            if constexpr (EPI == V2A_EPI_GATE_RESID) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
         }
@@ -521,6 +568,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     }
   };
 
+  constexpr bool PF = BM * BN <= 128 * 256;   // the 256x256 tile has no registers to spare (128 accumulators per lane)
+  EpiPrefetch<EPI, TM, WN, PF> pf;
+  if (p.vec_epi) pf.load(p, m0 + wm * WM, n0 + wn * WN, lane);
   const int nk = p.K / 64;
   // ring of NST stages (3: two tiles in flight while one is computed; 2: the 256x256 tile, whose 64 KB stages leave
   // room for only two)
@@ -568,7 +618,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     __builtin_amdgcn_s_barrier();   // every wave is done reading the K-loop stages; all DMAs were retired above
     static_assert(NW * 16 * (WN + 4) * 4 <= NST * STAGE_BYTES, "epilogue slabs must fit in the ring memory");
     float* tile = reinterpret_cast<float*>(smem_raw) + wave * (16 * (WN + 4));
-    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane);
+    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN, PF>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane, pf);
   } else {
     gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
   }
