@@ -89,6 +89,8 @@ typedef struct v2a_gemm_args {
    * replaces a separate v2a_rope_inplace(layout 0) pass over the fused [q|k|v|gate] output */
   const float* rope_table;
   int32_t rope_cols, rope_pos_offset;
+  int32_t relu;          /* non-zero: out = max(out, 0) after the epilogue (not GEGLU): the conv + folded-BatchNorm + ReLU
+                          * and conv + BN + residual + ReLU blocks of the Video2Roll encoder, Video2RollNet.py:70-88 */
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
@@ -199,6 +201,53 @@ int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C,
 int v2a_cast_bf16(const float* x, void* y, int64_t n, v2a_stream_t stream);
 /* step[0] += 1 (own launch: every block of the step has read step[0] before it runs) */
 int v2a_step_advance(int32_t* step, v2a_stream_t stream);
+
+/* =======================================================================================
+ * N2: Video2Roll frame encoder -- `E2TTS.encode_frames` x3:1525-1553 running
+ * `Video2RollNet.resnet18` (`v2r` = src/audeo/Video2RollNet.py:127-251).  Activations are NHWC fp32;
+ * every convolution is v2a_im2col (patch matrix in the compute dtype) + v2a_gemm with the eval-mode BatchNorm
+ * folded into the weights / bias and ReLU / residual in the epilogue.
+ * ===================================================================================== */
+
+/* Patch matrix of a 2-D convolution:  col[(n*Ho + yo)*Wo + xo][k],  zero outside the image and for k >= K.
+ *   window_t == 0: x is NHWC fp32 (n < B), k = (ky*kw + kx)*C + c, C % 4 == 0
+ *                  (replaces the unfold of nn.Conv2d at v2r:9-12,18-19,138,187-188)
+ *   window_t  > 0: x is (B / window_t clips, window_t frames, H, W) single-channel fp32 and the C = 5 input channels of
+ *                  window n = (clip, i) are frames clamp(i-2 .. i+2, 0, window_t-1) of that clip -- the 5-frame stack
+ *                  built at x3:1531-1539 is never materialised; k = (c*kh + ky)*kw + kx (the conv1 weight's own order)
+ * ldo = padded K (multiple of 64 for bf16, 16 for f32), out_dtype = V2A_F32 | V2A_BF16. */
+int v2a_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride,
+               int32_t pad, int32_t Ho, int32_t Wo, void* col, int64_t ldo, int32_t out_dtype, int32_t window_t,
+               int32_t window_first, v2a_stream_t stream);
+
+/* NHWC fp32 pooling: mode 0 = max (padding acts as -inf; nn.MaxPool2d(3, 2, 1) v2r:141), mode 1 = average over the full
+ * k*k window (nn.AvgPool2d(2, 2) / (3, 1), pad 0, v2r:22-23).  C % 4 == 0. */
+int v2a_pool2d(const float* x, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
+               int32_t pad, int32_t mode, int32_t Ho, int32_t Wo, v2a_stream_t stream);
+
+/* Fused top of the network (v2r:224-249 + the sigmoid of x3:1541), one workgroup per window:
+ *   FRB4/3/2 channel gates (global average pool -> fc1 -> ReLU -> fc2 -> sigmoid, v2r:44-57), out1 = p2*p3, softmax over
+ *   the P positions per channel, out2 = softmax*p4, conv2 (1x1) + p4, global average pool, fc, optional sigmoid.
+ * The 1x1 conv and the pool commute, so only per-channel position sums are formed.  All tensors fp32; x2_, x3_, x4_ are
+ * (B, P, 128) and x5 is (B, P, 64) NHWC maps; weights are TRANSPOSED ([in][out]) so lanes read consecutive outputs. */
+typedef struct v2a_roll_head_args {
+  const float *x2, *x3, *x4, *x5;
+  int32_t B, P;
+  const float *frb4_w1t, *frb4_b1, *frb4_w2t, *frb4_b2;   /* [192][128], [128], [128][128], [128] */
+  const float *frb3_w1t, *frb3_b1, *frb3_w2t, *frb3_b2;   /* [256][128] ...                        */
+  const float *frb2_w1t, *frb2_b1, *frb2_w2t, *frb2_b2;   /* [256][128] ...                        */
+  const float *conv2_wt, *conv2_b;                        /* [128][128], [128]                     */
+  const float *fc_wt, *fc_b;                              /* [128][notes], [notes]                 */
+  int32_t notes;                                          /* <= 128 (51: NOTES, x3:1523)           */
+  int32_t apply_sigmoid;                                  /* 1: probabilities (encode_frames), 0: logits (ResNet.forward) */
+  float* out;                                             /* (B, notes)                            */
+} v2a_roll_head_args;
+int v2a_roll_head(const v2a_roll_head_args* args, v2a_stream_t stream);
+
+/* roll (B, t, notes) -> out (B, l, notes): every frame row repeated `rep` (3) times, cropped / zero-padded to l rows
+ * (x3:1544-1553) */
+int v2a_roll_expand(const float* roll, float* out, int32_t B, int32_t t, int32_t notes, int32_t rep, int32_t l,
+                    v2a_stream_t stream);
 
 #ifdef __cplusplus
 }

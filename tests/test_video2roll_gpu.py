@@ -1,0 +1,227 @@
+"""GPU parity of the Video2Roll frame encoder through the C ABI.
+
+Checked against (a) vectors produced by the REFERENCE module (tests/golden/video2roll_*.npz, made by
+oracle/make_golden_video2roll.py running src/audeo/Video2RollNet.py), (b) the CPU restatement
+oracle/video2roll_oracle.py on seeded inputs, (c) plain torch ops for the individual kernels.
+Tolerances: fp32 mode -- logits (|x| up to ~17) 2e-3 abs, probabilities 1e-4 abs, feature maps 1e-4 rel
+(fp32 summation-order and BatchNorm-folding noise only); bf16 mode -- stated in each test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import video2roll_oracle as VO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PARAM_SEED, INPUT_SEED = 4321, 77
+
+
+@pytest.fixture(scope="module")
+def L():
+    from v2a_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def params():
+    from v2a_amd.synth import random_video2roll_state_dict
+    return random_video2roll_state_dict(PARAM_SEED)
+
+
+@pytest.fixture(scope="module")
+def engines(params):
+    from v2a_amd.video2roll import Video2RollEngine
+    return {c: Video2RollEngine(params, DEV, compute=c, chunk=3) for c in ("fp32", "bf16")}
+
+
+def _g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------- im2col
+@pytest.mark.parametrize("geom", [(3, 3, 1, 1), (3, 3, 2, 1), (1, 1, 1, 1), (1, 1, 2, 0), (1, 1, 1, 0)])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_im2col_nhwc_matches_unfold(L, geom, odt):
+    kh, kw, stride, pad = geom
+    B, H, W, C = 2, 7, 13, 64
+    x = torch.randn(B, C, H, W, generator=_g(kh * 10 + stride))
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    K = kh * kw * C
+    kpad = (K + 63) // 64 * 64 + 64                              # one extra zero block
+    col = torch.full((B * Ho * Wo, kpad), 7.0, dtype=odt, device=DEV)
+    L.im2col(x.permute(0, 2, 3, 1).contiguous().to(DEV), col, B=B, H=H, W=W, C_=C, kh=kh, kw=kw, stride=stride, pad=pad,
+             Ho=Ho, Wo=Wo, ldo=kpad)
+    # F.unfold orders k as (c, ky, kx); ours is (ky, kx, c)
+    u = F.unfold(x, (kh, kw), padding=pad, stride=stride).view(B, C, kh * kw, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, K)
+    ref = u if odt == torch.float32 else u.to(torch.bfloat16).float()
+    got = col.float().cpu()
+    assert torch.equal(got[:, :K], ref)                          # a gather: exact (bf16: same rounding)
+    assert torch.all(got[:, K:] == 0)
+
+
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_im2col_window_gathers_clamped_frames(L, odt):
+    clips, T, H, W = 2, 4, 12, 21
+    frames = torch.rand(clips, T, H, W, generator=_g(2))
+    kh = kw = 11
+    stride, pad = 2, 4
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    K = 5 * kh * kw
+    kpad = (K + 63) // 64 * 64
+    win = VO.frame_windows(frames[:, None])                       # (clips*T, 5, H, W), x3:1531-1539 restated
+    u = F.unfold(win, (kh, kw), padding=pad, stride=stride).permute(0, 2, 1).reshape(clips * T * Ho * Wo, K)
+    ref = u if odt == torch.float32 else u.to(torch.bfloat16).float()
+    for first, n in ((0, clips * T), (3, 4)):                     # all windows; a chunk straddling the clip boundary
+        col = torch.full((n * Ho * Wo, kpad), 7.0, dtype=odt, device=DEV)
+        L.im2col(frames.to(DEV), col, B=n, H=H, W=W, C_=5, kh=kh, kw=kw, stride=stride, pad=pad, Ho=Ho, Wo=Wo, ldo=kpad,
+                 window_t=T, window_first=first)
+        got = col.float().cpu()
+        assert torch.equal(got[:, :K], ref[first * Ho * Wo:(first + n) * Ho * Wo])
+        assert torch.all(got[:, K:] == 0)
+
+
+def test_im2col_rejects_bad_geometry(L):
+    x = torch.zeros(1, 4, 4, 8, device=DEV)
+    col = torch.zeros(16, 128, device=DEV)
+    with pytest.raises(L.V2AError, match="Ho/Wo"):
+        L.im2col(x, col, B=1, H=4, W=4, C_=8, kh=3, kw=3, stride=1, pad=1, Ho=3, Wo=4, ldo=128)
+    with pytest.raises(L.V2AError, match="C %% 4|C % 4"):
+        L.im2col(x, col, B=1, H=4, W=4, C_=6, kh=1, kw=1, stride=1, pad=0, Ho=4, Wo=4, ldo=128)
+
+
+# ------------------------------------------------------------------------------- pooling
+@pytest.mark.parametrize("cfg", [(3, 2, 1, 0), (2, 2, 0, 1), (3, 1, 0, 1)])
+def test_pool2d_matches_torch(L, cfg):
+    k, stride, pad, mode = cfg
+    B, H, W, C = 2, 9, 15, 64
+    x = torch.randn(B, C, H, W, generator=_g(k))
+    ref = F.max_pool2d(x, k, stride, pad) if mode == 0 else F.avg_pool2d(x, k, stride)
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty(B, Ho, Wo, C, device=DEV)
+    L.pool2d(x.permute(0, 2, 3, 1).contiguous().to(DEV), out, B=B, H=H, W=W, C_=C, k=k, stride=stride, pad=pad, mode=mode, Ho=Ho, Wo=Wo)
+    torch.testing.assert_close(out.cpu().permute(0, 3, 1, 2), ref, atol=1e-6, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------- GEMM relu flag
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+@pytest.mark.parametrize("N", [64, 128, 512])
+def test_gemm_relu_and_residual_relu(L, compute, N):
+    M, K = 700, 576
+    cd = torch.float32 if compute == "fp32" else torch.bfloat16
+    code = L.F32 if compute == "fp32" else L.BF16
+    a = torch.randn(M, K, generator=_g(1)).to(cd)
+    w = (torch.randn(N, K, generator=_g(2)) / K ** 0.5).to(cd)
+    b = torch.randn(N, generator=_g(3))
+    r = torch.randn(M, N, generator=_g(4))
+    acc = a.float() @ w.float().t() + b
+    tol = 2e-5 if compute == "fp32" else 2e-3
+    out = torch.empty(M, N, device=DEV)
+    L.gemm([(a.to(DEV), K, K)], w.to(DEV), out, M=M, N=N, compute=code, bias=b.to(DEV), relu=True)
+    torch.testing.assert_close(out.cpu(), acc.clamp_min(0), atol=tol, rtol=tol)
+    L.gemm([(a.to(DEV), K, K)], w.to(DEV), out, M=M, N=N, compute=code, epilogue=L.EPI_RESID, bias=b.to(DEV), resid=r.to(DEV), relu=True)
+    torch.testing.assert_close(out.cpu(), (acc + r).clamp_min(0), atol=tol, rtol=tol)
+    assert (out >= 0).all()
+
+
+# ------------------------------------------------------------------------------- fused head
+def test_roll_head_matches_reference_tail(L, params, engines):
+    """v2r:224-249 on random pyramid maps: FRB gates, spatial softmax, conv2 + pool + fc (pool / 1x1-conv commuted)."""
+    n, Hh, Ww = 3, 4, 29
+    g = _g(11)
+    x2_, x3_, x4_ = (torch.randn(n, 128, Hh, Ww, generator=g) for _ in range(3))
+    x5 = torch.randn(n, 64, Hh, Ww, generator=g).clamp_min(0)
+    P = params
+    p4 = VO.frb(P, "FRB4", x4_, x5)
+    p3 = VO.frb(P, "FRB3", x3_, p4)
+    p2 = VO.frb(P, "FRB2", x2_, p3)
+    out1 = p2 * p3
+    a = F.softmax(out1.flatten(2), dim=2).view_as(out1)
+    o = F.conv2d(a * p4, P["conv2.weight"], P["conv2.bias"]) + p4
+    ref = F.linear(o.mean((2, 3)), P["fc.weight"], P["fc.bias"])
+    eng = engines["fp32"]
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    bufs = [nhwc(t) for t in (x2_, x3_, x4_, x5)]
+    for sig in (0, 1):
+        args = L.RollHeadArgs()
+        args.x2, args.x3, args.x4, args.x5 = (b.data_ptr() for b in bufs)
+        args.B, args.P = n, Hh * Ww
+        for k, v in eng.head_w.items():
+            setattr(args, k, v.data_ptr())
+        out = torch.empty(n, 51, device=DEV)
+        args.notes, args.apply_sigmoid, args.out = 51, sig, out.data_ptr()
+        L.roll_head(args)
+        torch.testing.assert_close(out.cpu(), torch.sigmoid(ref) if sig else ref, atol=2e-5, rtol=2e-5)
+
+
+# ------------------------------------------------------------------------------- whole network vs the reference vectors
+def _windows_0_3_6():
+    from v2a_amd.synth import synthetic_piano_frames
+    return VO.frame_windows(synthetic_piano_frames(1, 7, seed=INPUT_SEED))[[0, 3, 6]]
+
+
+def test_forward_fp32_matches_reference_vectors(engines):
+    g = np.load(os.path.join(GOLD, "video2roll_forward.npz"))
+    taps = {}
+    logits = engines["fp32"].forward_windows(_windows_0_3_6(), taps).cpu().numpy()
+    err = np.abs(logits - g["logits"]).max()
+    print(f"\nvideo2roll fp32 vs reference logits: max |d| = {err:.3e} (|logit| max {np.abs(g['logits']).max():.1f})")
+    assert err < 2e-3
+    for k in ("x1", "x2", "x3", "x4", "x5", "x2_", "x3_", "x4_"):
+        a = torch.cat(taps[k], 0).cpu().numpy()
+        assert tuple(g[f"{k}_shape"]) == a.shape
+        np.testing.assert_allclose(a[tuple(g[f"{k}_idx"].T)], g[f"{k}_val"], rtol=1e-4, atol=1e-4)
+        assert np.abs(a).mean(dtype=np.float64) == pytest.approx(g[f"{k}_stats"][1], rel=1e-4)
+
+
+def test_forward_bf16_close_to_reference_vectors(engines):
+    """bf16 operands, fp32 accumulation through 21 conv layers: logits of magnitude ~17 within 0.35 abs / 3 % of range."""
+    g = np.load(os.path.join(GOLD, "video2roll_forward.npz"))
+    logits = engines["bf16"].forward_windows(_windows_0_3_6()).cpu().numpy()
+    err = np.abs(logits - g["logits"])
+    print(f"\nvideo2roll bf16 vs reference logits: max |d| = {err.max():.3e}, mean {err.mean():.3e}")
+    assert err.max() < 0.35 and err.mean() < 0.08
+
+
+@pytest.mark.parametrize("l", [10, 14])
+def test_encode_frames_fp32_matches_reference_lines(engines, l):
+    from v2a_amd.synth import synthetic_piano_frames
+    g = np.load(os.path.join(GOLD, "video2roll_encode.npz"))
+    x = synthetic_piano_frames(2, 4, seed=INPUT_SEED + 1)
+    roll = engines["fp32"].encode_frames(x, l)
+    assert roll.shape == (2, l, 51) and roll.dtype == torch.float32 and roll.is_cuda
+    np.testing.assert_allclose(roll.cpu().numpy(), g[f"roll_l{l}"], rtol=0, atol=1e-4)
+    if l == 14:
+        assert torch.all(roll[:, 12:] == 0)
+
+
+def test_encode_frames_bf16_and_chunking(params):
+    """bf16 probabilities within 0.03 of the fp32 restatement; the chunk size never changes a result bit."""
+    from v2a_amd.synth import synthetic_piano_frames
+    from v2a_amd.video2roll import Video2RollEngine
+    x = synthetic_piano_frames(1, 9, seed=5)
+    with torch.no_grad():
+        ref = VO.encode_frames(params, x, 30)
+    a = Video2RollEngine(params, DEV, compute="bf16", chunk=4).encode_frames(x, 30)
+    b = Video2RollEngine(params, DEV, compute="bf16", chunk=9).encode_frames(x, 30)
+    assert torch.equal(a, b)
+    err = (a.cpu() - ref).abs()
+    print(f"\nvideo2roll bf16 encode_frames vs CPU restatement: max {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() < 0.03 and err.mean() < 0.004
+    assert torch.all(a[:, 27:] == 0)
+
+
+def test_engine_rejects_incomplete_state_dict(params):
+    from v2a_amd.video2roll import Video2RollEngine
+    sd = dict(params)
+    sd.pop("FTB3.conv1.weight")
+    with pytest.raises(KeyError, match="FTB3.conv1.weight"):
+        Video2RollEngine(sd, DEV)
+    sd = dict(params)
+    sd["fc.weight"] = torch.zeros(51, 64)
+    with pytest.raises(ValueError, match="fc.weight"):
+        Video2RollEngine(sd, DEV)

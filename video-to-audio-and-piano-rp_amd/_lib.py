@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
         ("resid", C.c_void_p), ("ldr", C.c_int64),
         ("gate", C.c_void_p), ("step", C.c_void_p),
         ("gate_step_stride", C.c_int64), ("gate_batch_stride", C.c_int64), ("rows_per_batch", C.c_int32),
-        ("rope_table", C.c_void_p), ("rope_cols", C.c_int32), ("rope_pos_offset", C.c_int32),
+        ("rope_table", C.c_void_p), ("rope_cols", C.c_int32), ("rope_pos_offset", C.c_int32), ("relu", C.c_int32),
     ]
 
 
@@ -55,10 +55,18 @@ class AttnArgs(C.Structure):
     ]
 
 
+class RollHeadArgs(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("x2", "x3", "x4", "x5")] + [("B", C.c_int32), ("P", C.c_int32)] +
+                [(f"frb{i}_{n}", C.c_void_p) for i in (4, 3, 2) for n in ("w1t", "b1", "w2t", "b2")] +
+                [(n, C.c_void_p) for n in ("conv2_wt", "conv2_b", "fc_wt", "fc_b")] +
+                [("notes", C.c_int32), ("apply_sigmoid", C.c_int32), ("out", C.c_void_p)])
+
+
 EXPORTS = [
     "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
+    "v2a_im2col", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
 ]
 
 
@@ -92,6 +100,10 @@ def _declare(lib):
     lib.v2a_cfg_euler.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, f32, vp]
     lib.v2a_step_advance.argtypes = [vp, vp]
     lib.v2a_cast_bf16.argtypes = [vp, vp, i64, vp]
+    lib.v2a_im2col.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, i32, i32, vp]
+    lib.v2a_pool2d.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.v2a_roll_head.argtypes = [C.POINTER(RollHeadArgs), vp]
+    lib.v2a_roll_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     for name in EXPORTS:
         if name not in ("v2a_abi_version", "v2a_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -187,7 +199,7 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 
 def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
-         out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0):
+         out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
     g = GemmArgs()
     for i, (t, lda, k) in enumerate(a_segs):
@@ -216,6 +228,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.rows_per_batch = rows_per_batch
     g.rope_table = _p(rope_table)
     g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
+    g.relu = 1 if relu else 0
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
@@ -291,3 +304,24 @@ def step_advance(step):
 
 def cast_bf16(x, y):
     _launch("cast_bf16", 0.0, x.numel() * 6, lambda: lib().v2a_cast_bf16(x.data_ptr(), y.data_ptr(), x.numel(), stream_ptr()))
+
+
+# ---- N2: Video2Roll frame encoder ----------------------------------------------------------------
+def im2col(x, col, *, B, H, W, C_, kh, kw, stride, pad, Ho, Wo, ldo, window_t=0, window_first=0):
+    K = kh * kw * C_
+    _launch("im2col<%s>" % ("f32" if col.dtype == torch.float32 else "bf16"), 0.0, B * Ho * Wo * (4.0 * K + col.element_size() * ldo),
+            lambda: lib().v2a_im2col(x.data_ptr(), B, H, W, C_, kh, kw, stride, pad, Ho, Wo, col.data_ptr(), ldo,
+                                     dt_code(col.dtype), window_t, window_first, stream_ptr()))
+
+
+def pool2d(x, out, *, B, H, W, C_, k, stride, pad, mode, Ho, Wo):
+    _launch("pool2d", 0.0, 4.0 * B * C_ * (H * W + Ho * Wo),
+            lambda: lib().v2a_pool2d(x.data_ptr(), out.data_ptr(), B, H, W, C_, k, stride, pad, mode, Ho, Wo, stream_ptr()))
+
+
+def roll_head(args: "RollHeadArgs"):
+    _launch("roll_head", 0.0, 4.0 * args.B * args.P * (3 * 128 + 64), lambda: lib().v2a_roll_head(C.byref(args), stream_ptr()))
+
+
+def roll_expand(roll, out, *, B, t, notes, rep, l):
+    check(lib().v2a_roll_expand(roll.data_ptr(), out.data_ptr(), B, t, notes, rep, l, stream_ptr()))

@@ -36,6 +36,7 @@ struct GemmParams {
   const float* rope;     // cos/sin table [pos][32][2] or null: rotate interleaved pairs of columns < rope_cols (STORE epilogue)
   int32_t rope_cols, rope_pos_off;
   int32_t vec_epi;  // all epilogue pointers / strides allow 16-byte row pieces
+  int32_t relu;     // clamp the result at zero (conv + BatchNorm + ReLU blocks of the Video2Roll encoder)
 };
 
 template <typename T> struct TileCfg;
@@ -148,6 +149,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           if constexpr (EPI == V2A_EPI_SIGMOID) v = sigmoid_f(v);
           if constexpr (EPI == V2A_EPI_RESID) v += p.resid[(int64_t)m * p.ldr + n];
           if constexpr (EPI == V2A_EPI_GATE_RESID) v = p.resid[(int64_t)m * p.ldr + n] + gvec[n] * v;
+          if (p.relu) v = fmaxf(v, 0.f);
           out[(int64_t)m * p.ldo + n] = from_f32<OutT>(v);
           if constexpr (sizeof(OutT) == 4) {
             if (p.out2) p.out2[(int64_t)m * p.ldo2 + n] = (bf16_t)v;
@@ -297,6 +299,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if constexpr (sizeof(OutT) == 2) {
           bf16x4 o;
@@ -714,6 +720,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     if (a->out_bf16) ok = ok && ((uintptr_t)a->out_bf16 & 7) == 0 && a->ld_out_bf16 % 4 == 0;
     p.vec_epi = ok ? 1 : 0;
   }
+  p.relu = a->relu;
+  V2A_REQUIRE(!a->relu || a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: relu with GEGLU");
   p.rope = a->rope_table;
   p.rope_cols = a->rope_cols;
   p.rope_pos_off = a->rope_pos_offset;
@@ -737,6 +745,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   static const int big = getenv("V2A_GEMM_BIG") ? atoi(getenv("V2A_GEMM_BIG")) : 1;          // 0: never use the 256x256 tile
   int cfg;
   if (force >= 0) cfg = force;
+  else if (a->N <= 64) cfg = ntiles(128, 64) >= 512 ? 2 : 3;          // conv layers with few output channels
+  else if (a->N <= 128) cfg = ntiles(128, 128) >= 512 ? 1 : (ntiles(128, 64) >= 512 ? 2 : 3);
   else if (big && ntiles(256, 256) >= 512 && a->N >= 2048) cfg = 5;   // batched clips, wide outputs: halve the fill bytes per flop
   else if ((a->N >= 2048 && ntiles(128, 256) >= 96) || ntiles(128, 256) >= 200) cfg = 0;   // wide outputs, or large M
   else if (small >= 0) cfg = small;                                     // tuning aid: V2A_GEMM_SMALL

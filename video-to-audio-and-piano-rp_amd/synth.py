@@ -59,3 +59,57 @@ def synthetic_conditioning(cfg: DiTConfig, b: int, n: int = 750, nc: int = 16, s
     else:
         roll = torch.zeros(b, n, cfg.notes, device=device)
     return y0, text, roll, context, context_mask
+
+
+def random_video2roll_state_dict(seed: int = 0) -> dict[str, torch.Tensor]:
+    """Seeded weights in the key layout of `Video2RollNet.resnet18(num_classes=51)` (no piano checkpoint is reachable
+    offline: `./ckpts/piano5_4_2_8000.pt`, predict.py:68).  numpy's legacy RandomState stream, so the same seed gives the
+    same tensors on any machine / torch build (the golden vectors of tests/golden/video2roll_*.npz depend on that).
+    Conv weights follow the reference init N(0, sqrt(2 / (k*k*out))) (Video2RollNet.py:160-163); BatchNorm scale, shift
+    and running statistics are non-trivial so the folded-BatchNorm path is exercised."""
+    import numpy as np
+
+    from .video2roll import expected_state_dict_shapes
+
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for k, shp in expected_state_dict_shapes().items():
+        if k.endswith("num_batches_tracked"):
+            v = np.array(1000, dtype=np.int64)
+        elif k.endswith("running_var"):
+            v = rs.uniform(0.5, 1.5, shp).astype(np.float32)
+        elif k.endswith("running_mean"):
+            v = (0.1 * rs.standard_normal(shp)).astype(np.float32)
+        elif ("bn" in k or "downsample.1" in k) and k.endswith(".weight"):
+            v = (1.0 + 0.1 * rs.standard_normal(shp)).astype(np.float32)
+        elif k.endswith(".bias"):
+            v = (0.1 * rs.standard_normal(shp)).astype(np.float32)
+        elif len(shp) == 4:
+            v = (rs.standard_normal(shp) * math.sqrt(2.0 / (shp[2] * shp[3] * shp[0]))).astype(np.float32)
+        else:
+            v = (rs.standard_normal(shp) / math.sqrt(shp[-1])).astype(np.float32)
+        sd[k] = torch.from_numpy(v) if v.ndim else torch.tensor(int(v))
+    return sd
+
+
+def synthetic_piano_frames(b: int, t: int, H: int = 100, W: int = 900, seed: int = 0) -> torch.Tensor:
+    """(b, 1, t, H, W) grey frames in [0, 1] (ToTensor range, x3:1878-1890): a static keyboard-like stripe pattern plus a
+    few moving bright blobs and noise.  numpy RandomState, reproducible across machines."""
+    import numpy as np
+
+    rs = np.random.RandomState(seed)
+    xs = np.arange(W, dtype=np.float32)[None, :]
+    ys = np.arange(H, dtype=np.float32)[:, None]
+    base = 0.55 + 0.35 * np.sign(np.sin(xs * (2 * np.pi / 17.3))) * (ys > 0.35 * H)
+    out = np.empty((b, 1, t, H, W), dtype=np.float32)
+    for bi in range(b):
+        cx = rs.uniform(0, W, 6)
+        vx = rs.uniform(-6, 6, 6)
+        cy = rs.uniform(0.3 * H, H, 6)
+        for ti in range(t):
+            f = base.copy()
+            for j in range(6):
+                f += 0.4 * np.exp(-(((xs - (cx[j] + vx[j] * ti) % W) / 14.0) ** 2 + ((ys - cy[j]) / 9.0) ** 2))
+            f += 0.03 * rs.standard_normal((H, W)).astype(np.float32)
+            out[bi, 0, ti] = np.clip(f, 0.0, 1.0)
+    return torch.from_numpy(out)
