@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--shapes", action="store_true", help="print a per-GEMM-shape timing table to stderr")
     ap.add_argument("--no-batched", action="store_true", help="skip the supplementary 8-clips-per-GPU measurement (N=1 only)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="grid points of the bounded CPU sample")
+    ap.add_argument("--no-video2roll", action="store_true", help="skip the supplementary Video2Roll frame-encoder measurement (SURVEY 8f N2)")
+    ap.add_argument("--video2roll-frames", type=int, default=251, help="video frames per clip: floor(750 / 3) + 1 (x3:1913)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +175,9 @@ def main():
             one_step()                                     # restore the B=1 plan (and its graph) after the batched leg
             res["roofline"] = roofline_leg(model, L, y0, args)
             log("roofline leg done")
+        if not args.no_video2roll:
+            res["video2roll"] = video2roll_leg(L, args, dev, cpu=not args.no_cpu_baseline)
+            log("video2roll leg done")
         if not args.no_cpu_baseline:
             res.update(cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T))
     if rank == 0:
@@ -180,6 +185,61 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def video2roll_leg(L, args, dev, cpu=True):
+    """Supplementary: the V2P frame encoder (SURVEY 8f N2, x3:1525-1553) on one clip's 251 grey 100x900 frames --
+    outside the timed region of the headline metric, reported beside it.  Algorithmic work: 10.36 GFLOP per
+    5-frame window (2*MAC over the 21 convolutions of Video2RollNet.resnet18)."""
+    from v2a_amd.synth import random_video2roll_state_dict, synthetic_piano_frames
+    from v2a_amd.video2roll import Video2RollEngine
+    t = args.video2roll_frames
+    sd = random_video2roll_state_dict(0)
+    eng = Video2RollEngine(sd, dev, compute=args.dtype)
+    x = synthetic_piano_frames(1, t, seed=0).to(dev)
+    l = 3 * (t - 1)
+    eng.encode_frames(x, l)
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = eng.encode_frames(x, l)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    assert out.shape == (1, l, 51) and bool(torch.isfinite(out).all())
+    prof = L.KernelProfiler()
+    L.set_profiler(prof)
+    eng.encode_frames(x, l)
+    L.set_profiler(None)
+    agg = prof.summary()
+    kern = {}
+    tot_ms = sum(a["ms"] for a in agg.values())
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        e = {"launches": a["launches"], "ms": round(a["ms"], 3), "share": round(a["ms"] / tot_ms, 4)}
+        if a["flops"] > 0:
+            e["tflops"] = round(a["flops"] / a["ms"] / 1e9, 2)
+        else:
+            e["gbs"] = round(a["bytes"] / a["ms"] / 1e6, 1)
+        kern[k] = e
+    gflop_per_window = 10.36
+    res = {"frames": t, "ms_per_clip": round(el * 1e3, 2), "video_frames_per_s": round(t / el, 1),
+           "tflops": round(gflop_per_window * t / el / 1e3, 2), "dtype": args.dtype, "eager_kernel_ms": round(tot_ms, 2), "kernels": kern,
+           "note": "E2TTS.encode_frames on synthetic frames, seeded weights; outside the timed region of `value`"}
+    if cpu:
+        from oracle import video2roll_oracle as VO
+        torch.set_num_threads(host_cores())
+        n = 8
+        xc = x[:, :, :n].cpu()
+        with torch.no_grad():
+            VO.encode_frames(sd, xc[:, :, :2], 6)
+            t0 = time.perf_counter()
+            ref = VO.encode_frames(sd, xc, 3 * n)
+            cel = time.perf_counter() - t0
+        got = eng.encode_frames(x[:, :, :n], 3 * n).cpu()
+        res["cpu_baseline"] = {"value": round(n / cel, 2), "unit": "video-frames/s", "cores": host_cores(), "kind": "port",
+                               "sample": "%d windows of the same clip through oracle/video2roll_oracle.py (torch fp32)" % n}
+        res["parity_vs_cpu"] = {"max_abs": float((got - ref).abs().max()), "mean_abs": float((got - ref).abs().mean())}
+    return res
 
 
 def batched_leg(model, cfg, cfm_steps, args, T, NC, dev):

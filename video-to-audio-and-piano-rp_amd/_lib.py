@@ -14,7 +14,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libv2a_cfm.so")
+LIB_PATH = os.environ.get("V2A_CFM_LIB") or os.path.join(_HERE, "libv2a_cfm.so")   # V2A_CFM_LIB: A/B tuning aid
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1

@@ -25,21 +25,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   const float* xr = x + row * ldx;
   const float* g = step_vec(gamma, step, gss, gbs, row / rpb);
   const int nvec = d >> 2;
-  f32x4 v[VPL], gv[VPL];
+  f32x4 v[VPL];
   float ss = 0.f;
-  // every load of the row and of its scale vector is in flight before the first use: one memory latency per row
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = lane + 64 * i;
     if (c < nvec) {
       v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-      gv[i] = *reinterpret_cast<const f32x4*>(g + 4 * c);
+      ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
     }
-  }
-#pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
   }
   ss = wave_sum(ss);
   // F.normalize: x / max(||x||, eps), eps = 1e-12; then * sqrt(d)
@@ -49,15 +43,16 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   for (int i = 0; i < VPL; ++i) {
     const int c = lane + 64 * i;
     if (c < nvec) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * c);
       if constexpr (sizeof(OutT) == 4) {
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = v[i][j] * inv * gv[i][j];
+        for (int j = 0; j < 4; ++j) o[j] = v[i][j] * inv * gv[j];
         *reinterpret_cast<f32x4*>(yr + 4 * c) = o;
       } else {
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[i][j] * inv * gv[i][j]);
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[i][j] * inv * gv[j]);
         *reinterpret_cast<bf16x4*>(yr + 4 * c) = o;
       }
     }

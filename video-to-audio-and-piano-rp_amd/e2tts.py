@@ -26,6 +26,7 @@ from . import _lib as L
 from .dit import DiTConfig, DiTEngine, NOTES
 
 _IncompatibleKeys = namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+_V2R_PREFIX = "video2roll_net."
 
 
 def lens_to_mask(t: torch.Tensor, length: int | None = None) -> torch.Tensor:
@@ -189,6 +190,7 @@ class E2TTS:
         self._sd: dict[str, torch.Tensor] = {}
         self._engine: DiTEngine | None = None
         self._graphs: dict = {}
+        self._v2r_sd, self._v2r = None, None      # optional Video2Roll frame encoder (video2roll_net.*, x3:1523)
         L.lib()  # no library -> no sampler
 
     # ---- nn.Module-like surface used by the callers (predict.py:156-170) -------------------
@@ -199,6 +201,7 @@ class E2TTS:
     def to(self, device):
         self._device = torch.device(device)
         self._engine = None
+        self._v2r = None
         return self
 
     def eval(self):
@@ -209,7 +212,10 @@ class E2TTS:
         return iter(self._sd.values())
 
     def state_dict(self):
-        return dict(self._sd)
+        sd = dict(self._sd)
+        if self._v2r_sd is not None:
+            sd.update({_V2R_PREFIX + k: v for k, v in self._v2r_sd.items()})
+        return sd
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """Accepts a reference checkpoint's `model_state_dict` (predict.py:168, strict=False there):
@@ -224,7 +230,15 @@ class E2TTS:
                 new[k] = v.detach().to("cpu", torch.float32).contiguous()
             else:
                 missing.append(k)
-        unexpected = [k for k in state_dict if k not in self._shapes]
+        # optional: the Video2Roll frame encoder (`video2roll_net.*`, x3:1523) -- taken when the checkpoint holds it whole
+        v2r = {k[len(_V2R_PREFIX):]: v.detach().to("cpu") for k, v in state_dict.items() if k.startswith(_V2R_PREFIX)}
+        if v2r:
+            from .video2roll import expected_state_dict_shapes as v2r_shapes
+            lacking = [k for k in v2r_shapes() if k not in v2r and not k.endswith("num_batches_tracked")]
+            if lacking:
+                raise RuntimeError(f"load_state_dict: {_V2R_PREFIX}* is incomplete, e.g. {lacking[:3]}")
+            self._v2r_sd, self._v2r = v2r, None
+        unexpected = [k for k in state_dict if k not in self._shapes and not k.startswith(_V2R_PREFIX)]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict(strict=True): missing {missing[:5]}..., unexpected {unexpected[:5]}...")
         self._sd.update(new)
@@ -242,6 +256,17 @@ class E2TTS:
         return self._engine
 
     # ---- conditioning helpers ---------------------------------------------------------------
+    def encode_frames(self, x, l: int):
+        """x3:1525-1553: (b, 1, t, 100, 900) grey frames -> piano-roll probabilities (b, l, 51) on the HIP Video2Roll
+        encoder (video2roll.py); needs the `video2roll_net.*` weights of the checkpoint (load_state_dict)."""
+        if self._v2r_sd is None:
+            raise RuntimeError("encode_frames: no `video2roll_net.*` weights were loaded (load_state_dict), pass "
+                               "frames_embed= or frames_encoder_fn= instead")
+        if self._v2r is None:
+            from .video2roll import Video2RollEngine
+            self._v2r = Video2RollEngine(self._v2r_sd, self._device, compute=self._compute)
+        return self._v2r.encode_frames(x, l)
+
     def _get_context(self, prompt, context, context_mask, b):
         if context is None:
             if prompt is None:
@@ -332,9 +357,11 @@ class E2TTS:
                 frames_embed = torch.zeros(batch, cond_seq_len, cfgm.notes)
             elif self.frames_encoder_fn is not None:
                 frames_embed = self.frames_encoder_fn(frames, cond_seq_len)
+            elif self._v2r_sd is not None:
+                frames_embed = self.encode_frames(frames, cond_seq_len)     # x3:2169
             else:
-                raise NotImplementedError("Video2RollNet encode_frames is outside the accelerated path (SURVEY 8f N2): "
-                                          "pass frames_embed= or frames_encoder_fn=")
+                raise NotImplementedError("`frames` needs the Video2Roll encoder: load a checkpoint holding `video2roll_net.*`, "
+                                          "or pass frames_embed= / frames_encoder_fn=")
         if frames_embed.shape[1] < cond_seq_len:
             pad = torch.zeros(batch, cond_seq_len - frames_embed.shape[1], cfgm.notes, dtype=frames_embed.dtype, device=frames_embed.device)
             frames_embed = torch.cat([frames_embed, pad], 1)
