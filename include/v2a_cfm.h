@@ -91,6 +91,15 @@ typedef struct v2a_gemm_args {
   int32_t rope_cols, rope_pos_offset;
   int32_t relu;          /* non-zero: out = max(out, 0) after the epilogue (not GEGLU): the conv + folded-BatchNorm + ReLU
                           * and conv + BN + residual + ReLU blocks of the Video2Roll encoder, Video2RollNet.py:70-88 */
+  /* implicit-GEMM convolution (bf16 compute, one bf16 A segment, STORE / RESID epilogue): with a_row_offset the A row m
+   * starts at a[0] + a_row_offset[m] and K tile kt (64 elements) adds a_ktile_offset[kt] -- for an NHWC map stored with a
+   * zero border, a_row_offset = top-left tap of output pixel m and a_ktile_offset[kt] = (ky*Wp + kx)*C + c0, so the patch
+   * matrix of nn.Conv2d (Video2RollNet.py:9-12) is never materialised; lda is ignored.  With out_row_offset, row m of out,
+   * resid and out_bf16 starts at base + out_row_offset[m] (the interior of the next layer's bordered map) instead of m * ld.
+   * All offsets in elements, multiples of 8; NULL = dense rows. */
+  const int32_t* a_row_offset;
+  const int32_t* a_ktile_offset;
+  const int32_t* out_row_offset;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
@@ -221,9 +230,12 @@ int v2a_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32
                int32_t window_first, v2a_stream_t stream);
 
 /* NHWC fp32 pooling: mode 0 = max (padding acts as -inf; nn.MaxPool2d(3, 2, 1) v2r:141), mode 1 = average over the full
- * k*k window (nn.AvgPool2d(2, 2) / (3, 1), pad 0, v2r:22-23).  C % 4 == 0. */
-int v2a_pool2d(const float* x, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
-               int32_t pad, int32_t mode, int32_t Ho, int32_t Wo, v2a_stream_t stream);
+ * k*k window (nn.AvgPool2d(2, 2) / (3, 1), pad 0, v2r:22-23).  C % 4 == 0.  The input / output maps may be stored with a
+ * zero border of in_border / out_border pixels (the implicit-GEMM layout of v2a_gemm's offset tables): only interiors are
+ * read / written.  out_bf16 (or NULL) receives a bf16 copy with out's geometry (operand of the next convolution). */
+int v2a_pool2d(const float* x, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+               int32_t stride, int32_t pad, int32_t mode, int32_t Ho, int32_t Wo, int32_t in_border, int32_t out_border,
+               v2a_stream_t stream);
 
 /* Fused top of the network (v2r:224-249 + the sigmoid of x3:1541), one workgroup per window:
  *   FRB4/3/2 channel gates (global average pool -> fc1 -> ReLU -> fc2 -> sigmoid, v2r:44-57), out1 = p2*p3, softmax over

@@ -128,6 +128,70 @@ def test_gemm_relu_and_residual_relu(L, compute, N):
     assert (out >= 0).all()
 
 
+# ------------------------------------------------------------------------------- implicit-GEMM convolution (offset tables)
+@pytest.mark.parametrize("geom", [(3, 1, 1), (3, 2, 1), (1, 2, 0), (1, 1, 1)])
+@pytest.mark.parametrize("cout", [64, 128])
+def test_gemm_offset_tables_are_a_convolution(L, geom, cout):
+    """v2a_gemm with a_row_offset / a_ktile_offset / out_row_offset on zero-bordered NHWC bf16 maps == nn.Conv2d
+    (+bias, +residual, ReLU), including the 1x1 / padding=1 conv of FTB (v2r:18) and the stride-2 downsample (v2r:176)."""
+    k, stride, pad = geom
+    n, H, W, C, b = 3, 9, 14, 64, 1
+    g = _g(k * 7 + stride)
+    x = torch.randn(n, C, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, C, k, k, generator=g) / (C * k * k) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(cout, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(n, cout, Ho, Wo, generator=g)
+    ref = F.relu(F.conv2d(x.float(), w.float(), bias, stride, pad) + res)
+    Hp, Wp = H + 2 * b, W + 2 * b
+    xp = torch.zeros(n, Hp, Wp, C, dtype=torch.bfloat16)
+    xp[:, b:-b, b:-b] = x.permute(0, 2, 3, 1)
+    ni, yo, xo = torch.arange(n)[:, None, None], torch.arange(Ho)[None, :, None], torch.arange(Wo)[None, None, :]
+    a_row = (((ni * Hp + yo * stride - pad + b) * Wp + xo * stride - pad + b) * C).reshape(-1).int()
+    k0 = torch.arange(0, k * k * C, 64)
+    a_k = (((k0 // C) // k * Wp + (k0 // C) % k) * C + k0 % C).int()
+    ob = 1
+    o_row = ((((ni * (Ho + 2 * ob) + yo + ob) * (Wo + 2 * ob) + xo + ob) * cout).reshape(-1)).int()
+    rp = torch.zeros(n, Ho + 2, Wo + 2, cout)
+    rp[:, 1:-1, 1:-1] = res.permute(0, 2, 3, 1)
+    out = torch.full((n, Ho + 2, Wo + 2, cout), 5.0, device=DEV)
+    sh = torch.full((n, Ho + 2, Wo + 2, cout), 5.0, device=DEV, dtype=torch.bfloat16)
+    wk = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    K = k * k * C
+    L.gemm([(xp.to(DEV), K, K)], wk.to(DEV), out, M=n * Ho * Wo, N=cout, compute=L.BF16, epilogue=L.EPI_RESID, bias=bias.to(DEV),
+           resid=rp.to(DEV), relu=True, ldo=cout, ldr=cout, out_bf16=sh, ld_out_bf16=cout,
+           a_row_offset=a_row.to(DEV), a_ktile_offset=a_k.to(DEV), out_row_offset=o_row.to(DEV))
+    got = out.cpu()
+    torch.testing.assert_close(got[:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref, atol=2e-3, rtol=2e-3)
+    assert torch.all(got[:, 0] == 5) and torch.all(got[:, :, 0] == 5) and torch.all(got[:, -1] == 5) and torch.all(got[:, :, -1] == 5)
+    assert torch.equal(sh.cpu()[:, 1:-1, 1:-1], got[:, 1:-1, 1:-1].to(torch.bfloat16))      # border untouched, shadow = rounded out
+
+
+def test_gemm_offset_tables_need_the_bf16_path(L):
+    a = torch.zeros(64, 64, device=DEV)
+    w = torch.zeros(64, 64, device=DEV)
+    out = torch.zeros(64, 64, device=DEV)
+    t = torch.zeros(64, dtype=torch.int32, device=DEV)
+    with pytest.raises(L.V2AError, match="offset tables"):
+        L.gemm([(a, 64, 64)], w, out, M=64, N=64, compute=L.F32, a_row_offset=t, a_ktile_offset=t)
+
+
+def test_pool2d_bordered_maps_and_bf16_shadow(L):
+    B, H, W, C = 2, 9, 15, 64
+    x = torch.randn(B, C, H, W, generator=_g(9))
+    xp = torch.full((B, H + 2, W + 2, C), 99.0)          # a non-zero border must never be read (max pool pads with -inf)
+    xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    Ho, Wo = ref.shape[2:]
+    out = torch.zeros(B, Ho + 2, Wo + 2, C, device=DEV)
+    sh = torch.zeros(B, Ho + 2, Wo + 2, C, device=DEV, dtype=torch.bfloat16)
+    L.pool2d(xp.to(DEV), out, B=B, H=H, W=W, C_=C, k=3, stride=2, pad=1, mode=0, Ho=Ho, Wo=Wo, out_bf16=sh, in_border=1, out_border=1)
+    got = out.cpu()
+    assert torch.equal(got[:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref)
+    assert torch.all(got[:, 0] == 0) and torch.all(got[:, :, -1] == 0)
+    assert torch.equal(sh.cpu()[:, 1:-1, 1:-1], got[:, 1:-1, 1:-1].to(torch.bfloat16))
+
+
 # ------------------------------------------------------------------------------- fused head
 def test_roll_head_matches_reference_tail(L, params, engines):
     """v2r:224-249 on random pyramid maps: FRB gates, spatial softmax, conv2 + pool + fc (pool / 1x1-conv commuted)."""

@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("gate", C.c_void_p), ("step", C.c_void_p),
         ("gate_step_stride", C.c_int64), ("gate_batch_stride", C.c_int64), ("rows_per_batch", C.c_int32),
         ("rope_table", C.c_void_p), ("rope_cols", C.c_int32), ("rope_pos_offset", C.c_int32), ("relu", C.c_int32),
+        ("a_row_offset", C.c_void_p), ("a_ktile_offset", C.c_void_p), ("out_row_offset", C.c_void_p),
     ]
 
 
@@ -101,7 +102,7 @@ def _declare(lib):
     lib.v2a_step_advance.argtypes = [vp, vp]
     lib.v2a_cast_bf16.argtypes = [vp, vp, i64, vp]
     lib.v2a_im2col.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, i32, i32, vp]
-    lib.v2a_pool2d.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.v2a_pool2d.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.v2a_roll_head.argtypes = [C.POINTER(RollHeadArgs), vp]
     lib.v2a_roll_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     for name in EXPORTS:
@@ -199,7 +200,8 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 
 def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
-         out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False):
+         out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
+         a_row_offset=None, a_ktile_offset=None, out_row_offset=None):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
     g = GemmArgs()
     for i, (t, lda, k) in enumerate(a_segs):
@@ -229,6 +231,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.rope_table = _p(rope_table)
     g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
     g.relu = 1 if relu else 0
+    g.a_row_offset, g.a_ktile_offset, g.out_row_offset = _p(a_row_offset), _p(a_ktile_offset), _p(out_row_offset)
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
@@ -314,9 +317,10 @@ def im2col(x, col, *, B, H, W, C_, kh, kw, stride, pad, Ho, Wo, ldo, window_t=0,
                                      dt_code(col.dtype), window_t, window_first, stream_ptr()))
 
 
-def pool2d(x, out, *, B, H, W, C_, k, stride, pad, mode, Ho, Wo):
+def pool2d(x, out, *, B, H, W, C_, k, stride, pad, mode, Ho, Wo, out_bf16=None, in_border=0, out_border=0):
     _launch("pool2d", 0.0, 4.0 * B * C_ * (H * W + Ho * Wo),
-            lambda: lib().v2a_pool2d(x.data_ptr(), out.data_ptr(), B, H, W, C_, k, stride, pad, mode, Ho, Wo, stream_ptr()))
+            lambda: lib().v2a_pool2d(x.data_ptr(), out.data_ptr(), _p(out_bf16), B, H, W, C_, k, stride, pad, mode, Ho, Wo,
+                                     in_border, out_border, stream_ptr()))
 
 
 def roll_head(args: "RollHeadArgs"):

@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void im2col_window_kernel(const float* __restr
 
 // ---- pooling, NHWC fp32, one thread per (n, yo, xo, 4 channels) ---------------------------------------------------------
 template <bool MAX>
-__global__ __launch_bounds__(256) void pool2d_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t total, int H,
-                                                     int W, int C4, int k, int stride, int pad, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void pool2d_kernel(const float* __restrict__ x, float* __restrict__ out, bf16_t* __restrict__ out2,
+                                                     int64_t total, int H, int W, int C4, int k, int stride, int pad, int Ho, int Wo,
+                                                     int ib, int ob) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
   const int c4 = (int)(gid % C4);
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const float* __restrict__ x
   t /= Wo;
   const int yo = (int)(t % Ho);
   const int64_t n = t / Ho;
+  const int Hp = H + 2 * ib, Wp = W + 2 * ib;          // the maps may carry a zero border (implicit-GEMM layout)
   f32x4 acc = MAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
   for (int ky = 0; ky < k; ++ky) {
     const int yi = yo * stride - pad + ky;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const float* __restrict__ x
     for (int kx = 0; kx < k; ++kx) {
       const int xi = xo * stride - pad + kx;
       if (xi < 0 || xi >= W) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((n * H + yi) * W + xi) * C4 + c4) * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((n * Hp + yi + ib) * Wp + xi + ib) * C4 + c4) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] = MAX ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
     }
@@ -104,7 +106,9 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const float* __restrict__ x
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] *= inv;
   }
-  *reinterpret_cast<f32x4*>(out + gid * 4) = acc;
+  const int64_t o = (((n * (Ho + 2 * ob) + yo + ob) * (Wo + 2 * ob) + xo + ob) * C4 + c4) * 4;
+  *reinterpret_cast<f32x4*>(out + o) = acc;
+  if (out2) store4<bf16_t>(out2 + o, acc);
 }
 
 // ---- fused head: one workgroup of 128 threads (thread = channel) per window ---------------------------------------------
@@ -241,18 +245,22 @@ extern "C" int v2a_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32
   return v2a_check_launch("v2a_im2col");
 }
 
-extern "C" int v2a_pool2d(const float* x, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride,
-                          int32_t pad, int32_t mode, int32_t Ho, int32_t Wo, v2a_stream_t stream) {
+extern "C" int v2a_pool2d(const float* x, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
+                          int32_t stride, int32_t pad, int32_t mode, int32_t Ho, int32_t Wo, int32_t in_border, int32_t out_border,
+                          v2a_stream_t stream) {
   V2A_REQUIRE(x && out && x != out, "v2a_pool2d: null / aliased pointer");
   V2A_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && pad < k, "v2a_pool2d: bad geometry (C=%d k=%d)", C, k);
   V2A_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1, "v2a_pool2d: Ho/Wo mismatch");
   V2A_REQUIRE(mode == 0 || (mode == 1 && pad == 0), "v2a_pool2d: mode %d (average pooling is built for pad 0)", mode);
+  V2A_REQUIRE(in_border >= 0 && out_border >= 0 && ((uintptr_t)out_bf16 & 7) == 0, "v2a_pool2d: borders / bf16 alignment");
   const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (mode == 0)
-    hipLaunchKernelGGL((pool2d_kernel<true>), grid, block, 0, (hipStream_t)stream, x, out, total, H, W, C / 4, k, stride, pad, Ho, Wo);
+    hipLaunchKernelGGL((pool2d_kernel<true>), grid, block, 0, (hipStream_t)stream, x, out, (bf16_t*)out_bf16, total, H, W, C / 4, k,
+                       stride, pad, Ho, Wo, in_border, out_border);
   else
-    hipLaunchKernelGGL((pool2d_kernel<false>), grid, block, 0, (hipStream_t)stream, x, out, total, H, W, C / 4, k, stride, pad, Ho, Wo);
+    hipLaunchKernelGGL((pool2d_kernel<false>), grid, block, 0, (hipStream_t)stream, x, out, (bf16_t*)out_bf16, total, H, W, C / 4, k,
+                       stride, pad, Ho, Wo, in_border, out_border);
   return v2a_check_launch("v2a_pool2d");
 }
 

@@ -37,6 +37,11 @@ struct GemmParams {
   int32_t rope_cols, rope_pos_off;
   int32_t vec_epi;  // all epilogue pointers / strides allow 16-byte row pieces
   int32_t relu;     // clamp the result at zero (conv + BatchNorm + ReLU blocks of the Video2Roll encoder)
+  // implicit-GEMM convolution (DMA kernel only): A row m starts at a[0] + a_rowoff[m], K tile kt adds a_koff[kt] (elements);
+  // out / resid / out2 row m starts at base + o_rowoff[m] instead of m * ld
+  const int32_t* a_rowoff;
+  const int32_t* a_koff;
+  const int32_t* o_rowoff;
 };
 
 template <typename T> struct TileCfg;
@@ -202,7 +207,8 @@ template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
         for (int q = 0; q < RPS; ++q) {
           const int m = m_base + i * 16 + r0 + q * RPI;
           if (m < p.M && full) {
-            rs[i][q] = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+            const int64_t ro = p.o_rowoff ? (int64_t)p.o_rowoff[m] : (int64_t)m * p.ldr;
+            rs[i][q] = *reinterpret_cast<const f32x4*>(p.resid + ro + n);
             if constexpr (GATE) gt[i][q] = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
           }
         }
@@ -268,6 +274,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         const int r = r0 + q * RPI;
         const int m = m_base + i * 16 + r;
         if (m >= p.M || !full) continue;
+        const bool sc = p.o_rowoff != nullptr;          // scattered rows (implicit-GEMM convolution into a padded map)
+        const int64_t ro = sc ? (int64_t)p.o_rowoff[m] : 0;
+        const int64_t o_out = sc ? ro : (int64_t)m * p.ldo, o_res = sc ? ro : (int64_t)m * p.ldr, o_out2 = sc ? ro : (int64_t)m * p.ldo2;
         f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bv[e];
@@ -294,7 +303,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
             rs = pf.rs[i][q];
             if constexpr (EPI == V2A_EPI_GATE_RESID) gt = pf.gt[i][q];
           } else {
-            rs = *reinterpret_cast<const f32x4*>(p.resid + (int64_t)m * p.ldr + n);
+            rs = *reinterpret_cast<const f32x4*>(p.resid + o_res + n);
             if constexpr (EPI == V2A_EPI_GATE_RESID) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
           }
 #pragma unroll
@@ -308,14 +317,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
           bf16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x4*>(out + (int64_t)m * p.ldo + n) = o;
+          *reinterpret_cast<bf16x4*>(out + o_out + n) = o;
         } else {
-          *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldo + n) = v;
+          *reinterpret_cast<f32x4*>(out + o_out + n) = v;
           if (p.out2) {
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(p.out2 + (int64_t)m * p.ldo2 + n) = o;
+            *reinterpret_cast<bf16x4*>(p.out2 + o_out2 + n) = o;
           }
         }
       }
@@ -532,7 +541,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
       const int g = wave + i * NW;
-      goff[i] = (uint32_t)(((int64_t)grow[i] * (g < GA ? lda : p.ldw) + schunk) * 2);
+      const int64_t rbase = g < GA ? (p.a_rowoff ? (int64_t)p.a_rowoff[grow[i]] : (int64_t)grow[i] * lda) : (int64_t)grow[i] * p.ldw;
+      goff[i] = (uint32_t)((rbase + schunk) * 2);
     }
   };
 #pragma unroll
@@ -559,7 +569,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
       cur_seg = sgi;
       set_offsets(p.lda[sgi]);
     }
-    const char* ab = reinterpret_cast<const char*>(p.a[sgi]) + (int64_t)(k0 - kbeg) * 2;   // wave-uniform
+    const int64_t akoff = p.a_koff ? (int64_t)p.a_koff[kt] : (int64_t)(k0 - kbeg);       // wave-uniform (scalar load)
+    const char* ab = reinterpret_cast<const char*>(p.a[sgi]) + akoff * 2;
     const char* wb = wbase + (int64_t)k0 * 2;
     char* st = smem_raw + stage * STAGE_BYTES;
 #pragma unroll
@@ -721,6 +732,15 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     p.vec_epi = ok ? 1 : 0;
   }
   p.relu = a->relu;
+  p.a_rowoff = a->a_row_offset;
+  p.a_koff = a->a_ktile_offset;
+  p.o_rowoff = a->out_row_offset;
+  if (a->a_row_offset || a->a_ktile_offset || a->out_row_offset) {
+    V2A_REQUIRE((a->a_row_offset != nullptr) == (a->a_ktile_offset != nullptr), "v2a_gemm: a_row_offset and a_ktile_offset go together");
+    V2A_REQUIRE(a->nseg == 1 && a->compute_dtype == V2A_BF16 && a->a_dtype == V2A_BF16 && p.vec_epi &&
+                    (a->epilogue == V2A_EPI_STORE || a->epilogue == V2A_EPI_RESID) && !a->rope_table,
+                "v2a_gemm: row/K-tile offset tables need one bf16 segment, bf16 compute, STORE/RESID and 16-byte aligned rows");
+  }
   V2A_REQUIRE(!a->relu || a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: relu with GEGLU");
   p.rope = a->rope_table;
   p.rope_cols = a->rope_cols;

@@ -150,17 +150,36 @@ class Video2RollEngine:
         self.head_w["conv2_b"] = f32("conv2.bias")
         self.head_w["fc_wt"] = t32("fc.weight")
         self.head_w["fc_b"] = f32("fc.bias")
-        self._bufs: dict = {}
+        self._maps: dict = {}
+        self._tabs: dict = {}
         self._col = None
+        # bf16: implicit GEMM (the MFMA kernel gathers patch rows from zero-bordered NHWC bf16 maps through offset tables);
+        # fp32 parity mode: explicit patch matrix + the exact-fp32 GEMM.  The windowed first layer uses im2col in both.
+        self.implicit = compute == "bf16"
 
-    # ---- scratch ------------------------------------------------------------------------------
-    def _buf(self, name, *shape):
-        t = self._bufs.get(name)
-        n = math.prod(shape)
-        if t is None or t.numel() < n:
-            t = torch.empty(n, device=self.dev, dtype=torch.float32)
-            self._bufs[name] = t
-        return t[:n].view(*shape)
+    # ---- activation maps --------------------------------------------------------------------------
+    class _Map:
+        """NHWC fp32 activation (n, H + 2b, W + 2b, C) with a zero border of b pixels, plus its bf16 copy when a
+        convolution reads it (the DMA GEMM moves raw bf16 bytes)."""
+        __slots__ = ("f32", "b16", "n", "H", "W", "C", "border")
+
+        def __init__(self, f32, b16, n, H, W, C, border):
+            self.f32, self.b16, self.n, self.H, self.W, self.C, self.border = f32, b16, n, H, W, C, border
+
+        def interior(self):
+            b = self.border
+            return self.f32 if b == 0 else self.f32[:, b:-b, b:-b, :]
+
+    def _map(self, name, n, H, W, C, border=0, shadow=False):
+        """Cached by full geometry: a bordered map relies on its border staying zero, so two geometries never share memory."""
+        key = (name, n, H, W, C, border, shadow)
+        m = self._maps.get(key)
+        if m is None:
+            shp = (n, H + 2 * border, W + 2 * border, C)
+            f32 = torch.zeros(shp, device=self.dev, dtype=torch.float32)
+            b16 = torch.zeros(shp, device=self.dev, dtype=torch.bfloat16) if shadow else None
+            m = self._maps[key] = self._Map(f32, b16, n, H, W, C, border)
+        return m
 
     def _colbuf(self, rows, kpad):
         n = rows * kpad
@@ -168,100 +187,170 @@ class Video2RollEngine:
             self._col = torch.empty(n, device=self.dev, dtype=self.cd)
         return self._col[:n].view(rows, kpad)
 
-    # ---- one convolution: im2col + GEMM (+bias, +residual, +ReLU in the epilogue) ---------------------
-    def _conv(self, name, x, n, H, W, out_name, *, relu=False, resid=None, window=None):
+    def _tables(self, cv, src, Ho, Wo, out_border):
+        """Offset tables of one convolution geometry for v2a_gemm's implicit-GEMM mode (elements, int32)."""
+        key = (cv.kh, cv.kw, cv.stride, cv.pad, cv.ci, cv.co, src.n, src.H, src.W, src.border, out_border)
+        t = self._tabs.get(key)
+        if t is None:
+            b, C = src.border, cv.ci
+            assert b >= cv.pad, "the source map's zero border must cover the convolution's padding"
+            Hp, Wp = src.H + 2 * b, src.W + 2 * b
+            dev = self.dev
+            ni = torch.arange(src.n, device=dev, dtype=torch.int64)[:, None, None]
+            yo = torch.arange(Ho, device=dev, dtype=torch.int64)[None, :, None]
+            xo = torch.arange(Wo, device=dev, dtype=torch.int64)[None, None, :]
+            a_row = ((ni * Hp + yo * cv.stride - cv.pad + b) * Wp + xo * cv.stride - cv.pad + b) * C
+            k0 = torch.arange(0, cv.kh * cv.kw * C, 64, device=dev, dtype=torch.int64)
+            tap, c0 = k0 // C, k0 % C
+            a_k = ((tap // cv.kw) * Wp + tap % cv.kw) * C + c0
+            o_row = None
+            if out_border:
+                o_row = (((ni * (Ho + 2 * out_border) + yo + out_border) * (Wo + 2 * out_border) + xo + out_border) * cv.co)
+                o_row = o_row.reshape(-1).to(torch.int32).contiguous()
+            assert int(a_row.max()) + int(a_k.max()) + 64 <= src.n * Hp * Wp * C < 2 ** 31
+            t = self._tabs[key] = (a_row.reshape(-1).to(torch.int32).contiguous(), a_k.to(torch.int32).contiguous(), o_row)
+        return t
+
+    # ---- one convolution (+bias, +residual, +ReLU in the GEMM epilogue) ---------------------------------
+    def _conv(self, name, src, dst_name, *, relu=False, resid=None, border=None, shadow=None, window=None, dst=None):
         cv = self.convs[name]
+        if cv.window:
+            frames, T, first, n, H, W = window
+        else:
+            n, H, W = src.n, src.H, src.W
         Ho, Wo = cv.out_hw(H, W)
         rows = n * Ho * Wo
+        if border is None:
+            border = 1 if self.implicit else 0
+        if shadow is None:
+            shadow = self.implicit
+        if dst is None:
+            dst = self._map(dst_name, n, Ho, Wo, cv.co, border, shadow)
+        assert (dst.n, dst.H, dst.W, dst.C) == (n, Ho, Wo, cv.co)
+        if resid is not None:
+            assert (resid.n, resid.H, resid.W, resid.C, resid.border) == (dst.n, dst.H, dst.W, dst.C, dst.border)
+        epi = L.EPI_RESID if resid is not None else L.EPI_STORE
+        rs = None if resid is None else resid.f32
+        if self.implicit and not cv.window:
+            a_row, a_k, o_row = self._tables(cv, src, Ho, Wo, dst.border)
+            K = cv.kh * cv.kw * cv.ci
+            L.gemm([(src.b16, K, K)], cv.w, dst.f32, M=rows, N=cv.co, compute=self.code, epilogue=epi, bias=cv.bias, resid=rs,
+                   relu=relu, ldo=cv.co, ldr=cv.co, out_bf16=dst.b16, ld_out_bf16=cv.co,
+                   a_row_offset=a_row, a_ktile_offset=a_k, out_row_offset=o_row)
+            return dst
+        # explicit patch matrix
+        assert dst.border == 0 or cv.window is False
         col = self._colbuf(rows, cv.Kpad)
         if cv.window:
-            frames, T, first = window
             L.im2col(frames, col, B=n, H=H, W=W, C_=5, kh=cv.kh, kw=cv.kw, stride=cv.stride, pad=cv.pad, Ho=Ho, Wo=Wo,
                      ldo=cv.Kpad, window_t=T, window_first=first)
         else:
-            L.im2col(x, col, B=n, H=H, W=W, C_=cv.ci, kh=cv.kh, kw=cv.kw, stride=cv.stride, pad=cv.pad, Ho=Ho, Wo=Wo,
+            assert src.border == 0
+            L.im2col(src.f32, col, B=n, H=H, W=W, C_=cv.ci, kh=cv.kh, kw=cv.kw, stride=cv.stride, pad=cv.pad, Ho=Ho, Wo=Wo,
                      ldo=cv.Kpad)
-        out = self._buf(out_name, n, Ho, Wo, cv.co)
-        o2 = out.view(rows, cv.co)
-        L.gemm([(col, cv.Kpad, cv.Kpad)], cv.w, o2, M=rows, N=cv.co, compute=self.code,
-               epilogue=L.EPI_RESID if resid is not None else L.EPI_STORE, bias=cv.bias,
-               resid=None if resid is None else resid.view(rows, cv.co), relu=relu)
-        return out, Ho, Wo
+        L.gemm([(col, cv.Kpad, cv.Kpad)], cv.w, dst.f32, M=rows, N=cv.co, compute=self.code, epilogue=epi, bias=cv.bias, resid=rs,
+               relu=relu, ldo=cv.co, ldr=cv.co)
+        return dst
 
-    def _block(self, p, x, n, H, W, tag):
+    def _pool(self, src, dst_name, k, stride, pad, mode, *, border=0, shadow=False, dst=None):
+        Ho, Wo = (src.H + 2 * pad - k) // stride + 1, (src.W + 2 * pad - k) // stride + 1
+        if dst is None:
+            dst = self._map(dst_name, src.n, Ho, Wo, src.C, border, shadow)
+        L.pool2d(src.f32, dst.f32, B=src.n, H=src.H, W=src.W, C_=src.C, k=k, stride=stride, pad=pad, mode=mode, Ho=Ho, Wo=Wo,
+                 out_bf16=dst.b16, in_border=src.border, out_border=dst.border)
+        return dst
+
+    def _block(self, p, x):
         """BasicBlock (v2r:70-88)."""
-        h, Ho, Wo = self._conv(f"{p}.conv1", x, n, H, W, f"{tag}.h", relu=True)
+        h = self._conv(f"{p}.conv1", x, f"{p}.h", relu=True)
         res = x
         if f"{p}.down" in self.convs:
-            res, _, _ = self._conv(f"{p}.down", x, n, H, W, f"{tag}.down")
-        out, _, _ = self._conv(f"{p}.conv2", h, n, Ho, Wo, f"{tag}.out", relu=True, resid=res)
-        return out, Ho, Wo
+            res = self._conv(f"{p}.down", x, f"{p}.down", shadow=False)
+        return self._conv(f"{p}.conv2", h, f"{p}.out", relu=True, resid=res)
 
-    def _ftb(self, p, x, n, H, W, avg=True):
-        """FTB (v2r:24-36)."""
-        x1, H1, W1 = self._conv(f"{p}.conv0", x, n, H, W, f"{p}.x1")
-        h, _, _ = self._conv(f"{p}.conv1", x1, n, H1, W1, f"{p}.h", relu=True)
-        o, _, _ = self._conv(f"{p}.conv2", h, n, H1, W1, f"{p}.o", resid=x1)
+    def _ftb(self, p, x, avg=True, *, to_conv=False, dst=None):
+        """FTB (v2r:24-36): its 1x1 conv0 has padding=1 -- over a zero-bordered map that is a plain 1x1 conv of the border too."""
+        x1 = self._conv(f"{p}.conv0", x, f"{p}.x1")
+        h = self._conv(f"{p}.conv1", x1, f"{p}.h", relu=True)
+        o = self._conv(f"{p}.conv2", h, f"{p}.o", resid=x1, shadow=False)
         k, st = (2, 2) if avg else (3, 1)
-        Ho, Wo = (H1 - k) // st + 1, (W1 - k) // st + 1
-        out = self._buf(f"{p}.pool", n, Ho, Wo, 128)
-        L.pool2d(o, out, B=n, H=H1, W=W1, C_=128, k=k, stride=st, pad=0, mode=1, Ho=Ho, Wo=Wo)
-        return out, Ho, Wo
+        b = 1 if (to_conv and self.implicit) else 0
+        return self._pool(o, f"{p}.pool", k, st, 0, 1, border=b, shadow=b == 1, dst=dst)
 
-    def _windows(self, frames, T, first, n, H, W, out, sigmoid, taps=None):
-        """ResNet.forward (v2r:195-251) for windows [first, first + n) of frames (clips, T, H, W); writes out (n, notes)."""
-        c1, H1, W1 = self._conv("conv1", None, n, H, W, "c1", relu=True, window=(frames, T, first))
-        Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-        h = self._buf("mp", n, Hp, Wp, 64)
-        L.pool2d(c1, h, B=n, H=H1, W=W1, C_=64, k=3, stride=2, pad=1, mode=0, Ho=Hp, Wo=Wp)
+    def _windows(self, frames, T, first, n, H, W, head, row, taps=None):
+        """ResNet.forward up to the pyramid maps (v2r:195-222) for windows [first, first + n) of frames (clips, T, H, W);
+        the four maps the head needs land in rows [row, row + n) of the `head` buffers."""
+        c1 = self._conv("conv1", None, "c1", relu=True, border=0, shadow=False, window=(frames, T, first, n, H, W))
+        b = 1 if self.implicit else 0
+        h = self._pool(c1, "mp", 3, 2, 1, 0, border=b, shadow=self.implicit)
         feats = []
-        Hc, Wc = Hp, Wp
         for name, _, _ in _LAYERS:
-            h, Hc, Wc = self._block(f"{name}.0", h, n, Hc, Wc, f"{name}.0")
-            h, Hc, Wc = self._block(f"{name}.1", h, n, Hc, Wc, f"{name}.1")
-            feats.append((h, Hc, Wc))
-        (x1, _, _), (x2, H2, W2), (x3, H3, W3), (x4, H4, W4) = feats
-        x5, _, _ = self._conv("toplayer", x4, n, H4, W4, "x5", relu=True)
-        t, Ht, Wt = self._ftb("FTB2_1", x2, n, H2, W2)
-        x2_, Ha, Wa = self._ftb("FTB2_2", t, n, Ht, Wt)
-        x3_, Hb, Wb = self._ftb("FTB3", x3, n, H3, W3)
-        x4_, Hc4, Wc4 = self._ftb("FTB4", x4, n, H4, W4, avg=False)
-        if not ((Ha, Wa) == (Hb, Wb) == (Hc4, Wc4) == (H4, W4)):
-            raise L.V2AError(f"Video2Roll: pyramid maps disagree for a {H}x{W} input: {(Ha, Wa)}, {(Hb, Wb)}, {(Hc4, Wc4)}, {(H4, W4)}")
+            h = self._block(f"{name}.0", h)
+            h = self._block(f"{name}.1", h)
+            feats.append(h)
+        x1, x2, x3, x4 = feats
+        P = x4.H * x4.W
+        view = lambda k, C: self._Map(head[k][row:row + n].view(n, x4.H, x4.W, C), None, n, x4.H, x4.W, C, 0)
+        x5 = self._conv("toplayer", x4, "x5", relu=True, dst=view("x5", 64))
+        t = self._ftb("FTB2_1", x2, to_conv=True)
+        shapes = []
+        for nm, srcm, avg, key in (("FTB2_2", t, True, "x2"), ("FTB3", x3, True, "x3"), ("FTB4", x4, False, "x4")):
+            k, st = (2, 2) if avg else (3, 1)
+            shapes.append(((srcm.H + 2 - k) // st + 1, (srcm.W + 2 - k) // st + 1))
+        if any(sh != (x4.H, x4.W) for sh in shapes):
+            raise L.V2AError(f"Video2Roll: pyramid maps disagree for a {H}x{W} input: {shapes} vs {(x4.H, x4.W)}")
+        x2_ = self._ftb("FTB2_2", t, dst=view("x2", 128))
+        x3_ = self._ftb("FTB3", x3, dst=view("x3", 128))
+        x4_ = self._ftb("FTB4", x4, avg=False, dst=view("x4", 128))
+        if taps is not None:
+            nchw = lambda m: m.interior().permute(0, 3, 1, 2).clone()
+            for k, v in dict(c1=c1, x1=x1, x2=x2, x3=x3, x4=x4, x5=x5, x2_=x2_, x3_=x3_, x4_=x4_).items():
+                taps.setdefault(k, []).append(nchw(v))
+        return P
+
+    def _head_buffers(self, total, H, W):
+        cv = self.convs
+        h1, w1 = cv["conv1"].out_hw(H, W)
+        hc, wc = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
+        for _ in range(3):                                   # layer2..4 halve the map (3x3, stride 2, pad 1)
+            hc, wc = (hc + 2 - 3) // 2 + 1, (wc + 2 - 3) // 2 + 1
+        P = hc * wc
+        key = ("head", total, P)
+        hb = self._maps.get(key)
+        if hb is None:
+            e = lambda C: torch.empty(total, P, C, device=self.dev, dtype=torch.float32)
+            hb = self._maps[key] = dict(x2=e(128), x3=e(128), x4=e(128), x5=e(64))
+        return hb, P
+
+    def _run(self, frames, T, sigmoid, windows=None, taps=None):
+        """windows: explicit list of global window indices (tests), default all clips*T windows in chunks."""
+        clips, _, H, W = frames.shape
+        spans = [(f, min(self.chunk, clips * T - f)) for f in range(0, clips * T, self.chunk)] if windows is None else [(w, 1) for w in windows]
+        total = sum(n for _, n in spans)
+        head, P = self._head_buffers(total, H, W)
+        row = 0
+        for first, n in spans:
+            self._windows(frames, T, first, n, H, W, head, row, taps)
+            row += n
+        out = torch.empty(total, self.notes, device=self.dev, dtype=torch.float32)
         a = L.RollHeadArgs()
-        a.x2, a.x3, a.x4, a.x5 = x2_.data_ptr(), x3_.data_ptr(), x4_.data_ptr(), x5.data_ptr()
-        a.B, a.P = n, H4 * W4
+        a.x2, a.x3, a.x4, a.x5 = head["x2"].data_ptr(), head["x3"].data_ptr(), head["x4"].data_ptr(), head["x5"].data_ptr()
+        a.B, a.P = total, P
         for k, v in self.head_w.items():
             setattr(a, k, v.data_ptr())
         a.notes, a.apply_sigmoid, a.out = self.notes, 1 if sigmoid else 0, out.data_ptr()
         L.roll_head(a)
-        if taps is not None:
-            nchw = lambda v: v.permute(0, 3, 1, 2).clone()
-            for k, v in dict(c1=c1, x1=x1, x2=x2, x3=x3, x4=x4, x5=x5, x2_=x2_, x3_=x3_, x4_=x4_).items():
-                taps.setdefault(k, []).append(nchw(v))
-
-    def _run(self, frames, T, sigmoid, taps=None):
-        clips, _, H, W = frames.shape
-        total = clips * T
-        out = torch.empty(total, self.notes, device=self.dev, dtype=torch.float32)
-        for first in range(0, total, self.chunk):
-            n = min(self.chunk, total - first)
-            self._windows(frames, T, first, n, H, W, out[first:first + n], sigmoid, taps)
         return out
 
     # ---- reference-shaped entry points ----------------------------------------------------------------
     @torch.no_grad()
     def forward_windows(self, x, taps=None):
-        """`ResNet.forward` on explicit windows (n, 5, H, W) -> logits (n, notes) (v2r:195-251).  Each window is treated
-        as its own 5-frame clip whose centre frame sees exactly channels 0..4 (parity / test entry point)."""
+        """`ResNet.forward` on explicit windows (n, 5, H, W) -> logits (n, notes) (v2r:195-251).  Each window is loaded as
+        its own 5-frame clip; the clip's centre window (index 2) is exactly that un-clamped stack (parity / test entry)."""
         n, c, H, W = x.shape
         assert c == 5
         frames = x.to(self.dev, torch.float32).contiguous()          # (n clips, T = 5 frames, H, W)
-        out = torch.empty(n, self.notes, device=self.dev, dtype=torch.float32)
-        # window index 2 of every 5-frame clip is the un-clamped stack; run them one clip-centre at a time per chunk
-        for i in range(n):
-            self._windows(frames, 5, 5 * i + 2, 1, H, W, out[i:i + 1], False, taps)
-        return out
+        return self._run(frames, 5, False, windows=[5 * i + 2 for i in range(n)], taps=taps)
 
     @torch.no_grad()
     def encode_frames(self, x, l: int):
