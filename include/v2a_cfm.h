@@ -261,6 +261,28 @@ int v2a_roll_head(const v2a_roll_head_args* args, v2a_stream_t stream);
 int v2a_roll_expand(const float* roll, float* out, int32_t B, int32_t t, int32_t notes, int32_t rep, int32_t l,
                     v2a_stream_t stream);
 
+/* =======================================================================================
+ * N1: Encodec 24 kHz decoder, the vocoder behind `EncodecWrapper.decode` x3:434-437 (predict.py:277-278;
+ * arithmetic: transformers EncodecDecoder, requirements.txt:20).  Activations are time-major [T][C] fp32, so every
+ * causal Conv1d is a v2a_gemm over overlapping rows (lda = C, K = k*C) and every ConvTranspose1d(k = 2*stride) a v2a_gemm
+ * with K = 2C, N = stride*Cout whose output IS the up-sampled [T*stride][Cout] signal.  Two kernels complete the stack:
+ * ===================================================================================== */
+
+/* out[(pad + t)][c] = act ? ELU(x[t][c]) : x[t][c] for t < T, preceded by `pad` rows: reflect != 0 -> row (pad - i) mirrors
+ * row i (the causal reflect padding of EncodecConv1d: F.pad(x, (k-1, 0), "reflect")), else zeros (the x[q-1] operand of a
+ * transposed convolution at q = 0).  out holds (T + pad) rows.  C % 4 == 0.  Replaces nn.ELU + the padding of every conv. */
+int v2a_elu_pad(const float* x, float* out, int64_t T, int32_t C, int32_t pad, int32_t reflect, int32_t act,
+                v2a_stream_t stream);
+
+/* One nn.LSTM layer's recurrence over T steps (batch 1, hidden H = 512, zero initial state), gates in torch order (i,f,g,o):
+ *   g_t = gates_x[t] + W_hh h_{t-1};  c_t = sig(f) c_{t-1} + sig(i) tanh(g);  h_t = sig(o) tanh(c_t)
+ * gates_x[t] = W_ih x_t + b_ih + b_hh comes from a v2a_gemm.  h (T, H) receives every h_t; with y != NULL also
+ * y[t] = h_t + resid[t] (the skip of EncodecLSTM).  Persistent kernel of H/8 workgroups with W_hh in registers and a
+ * counter barrier per step; workspace = 2 int32 (zeroed by the call; workspace[1] != 0 afterwards means a workgroup timed
+ * out waiting for its peers and the result is invalid). */
+int v2a_lstm_layer(const float* gates_x, const float* w_hh, float* h, const float* resid, float* y, int32_t T, int32_t H,
+                   int32_t* workspace, v2a_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

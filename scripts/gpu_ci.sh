@@ -20,6 +20,7 @@ for s in "$@"; do
     sampler) run sampler 600 python -m pytest tests/test_sampler_gpu.py -q -m gpu -x --tb=short -s ;;
     sampler_all) run sampler 600 python -m pytest tests/test_sampler_gpu.py -q -m gpu --tb=short -s ;;
     v2r) run v2r 600 python -m pytest tests/test_video2roll_gpu.py -q -m gpu -x --tb=short -s ;;
+    enc) run enc 600 python -m pytest tests/test_encodec_gpu.py -q -m gpu -x --tb=short -s ;;
     full) run full 900 python -m pytest tests/test_full_shape_gpu.py -q -m gpu -x --tb=short -s ;;
     alltests) run alltests 1100 python -m pytest tests -q -m gpu -x --tb=short ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;

@@ -68,6 +68,7 @@ EXPORTS = [
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
     "v2a_im2col", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
+    "v2a_elu_pad", "v2a_lstm_layer",
 ]
 
 
@@ -105,6 +106,8 @@ def _declare(lib):
     lib.v2a_pool2d.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.v2a_roll_head.argtypes = [C.POINTER(RollHeadArgs), vp]
     lib.v2a_roll_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.v2a_elu_pad.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.v2a_lstm_layer.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     for name in EXPORTS:
         if name not in ("v2a_abi_version", "v2a_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -329,3 +332,15 @@ def roll_head(args: "RollHeadArgs"):
 
 def roll_expand(roll, out, *, B, t, notes, rep, l):
     check(lib().v2a_roll_expand(roll.data_ptr(), out.data_ptr(), B, t, notes, rep, l, stream_ptr()))
+
+
+# ---- N1: Encodec decoder (vocoder) ---------------------------------------------------------------
+def elu_pad(x, out, *, T, C_, pad, reflect, act=True):
+    _launch("elu_pad", 0.0, 4.0 * C_ * (2 * T + pad),
+            lambda: lib().v2a_elu_pad(x.data_ptr(), out.data_ptr(), T, C_, pad, 1 if reflect else 0, 1 if act else 0, stream_ptr()))
+
+
+def lstm_layer(gates_x, w_hh, h, workspace, *, T, H, resid=None, y=None):
+    _launch("lstm_layer", 2.0 * T * 4 * H * H, 4.0 * T * 6 * H,
+            lambda: lib().v2a_lstm_layer(gates_x.data_ptr(), w_hh.data_ptr(), h.data_ptr(), _p(resid), _p(y), T, H,
+                                         workspace.data_ptr(), stream_ptr()))

@@ -1,0 +1,142 @@
+// Encodec (24 kHz SEANet) decoder -- the vocoder behind `EncodecWrapper.decode` (x3:434-437, predict.py:277-278), SURVEY 8f N1.
+// Every convolution of the stack is a v2a_gemm call on a time-major [T][C] buffer (overlapping rows: lda = C, K = k*C;
+// transposed convolutions: K = 2C, N = stride*Cout), so only two kernels live here:
+//   * elu_pad:    out[pad + t] = ELU(x[t]) with `pad` reflected (causal Conv1d) or zero (ConvTranspose1d) rows in front;
+//   * lstm_layer: the recurrence of one nn.LSTM layer as a persistent kernel -- W_hh stays in registers across all T steps,
+//                 the H/8 workgroups exchange h_t through global memory and meet at a counter barrier once per step.
+#include "v2a_common.h"
+
+namespace {
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
+
+// one thread per float4 of the padded output
+__global__ __launch_bounds__(256) void elu_pad_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t T, int C4, int pad,
+                                                      int reflect, int act) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (T + pad) * C4) return;
+  const int64_t row = gid / C4;
+  const int c4 = (int)(gid - row * C4);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int64_t src = row - pad;
+  if (src < 0) src = reflect ? -src : -1;            // reflect: padded row (pad - i) mirrors row i, the edge row is not repeated
+  if (src >= 0) {
+    v = *reinterpret_cast<const f32x4*>(x + (src * C4 + c4) * 4);
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = elu_f(v[e]);
+    }
+  }
+  *reinterpret_cast<f32x4*>(out + gid * 4) = v;
+}
+
+// ---- LSTM recurrence -------------------------------------------------------------------------------
+// gx[t][4H] = W_ih x_t + b_ih + b_hh (a GEMM done by the caller); gates in torch order (i, f, g, o).
+// Workgroup w owns hidden units [8w, 8w+8): 32 rows of W_hh (4 gates x 8 units), thread (row = tid >> 3, seg = tid & 7) keeps
+// the H/8 weights of its row segment in registers for the whole sequence.  Per step: h_{t-1} (H floats, written by all
+// workgroups) -> LDS, 64 FMAs per thread, 8-lane reduction, cell update by 8 threads, h_t -> global, grid barrier.
+constexpr int LSTM_H = 512;
+constexpr int LSTM_SEG = LSTM_H / 8;       // 64 columns per thread
+constexpr int LSTM_SPIN_CAP = 1 << 22;     // polls before a workgroup gives up (a missing peer must not hang the GPU)
+
+__global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ gx, const float* __restrict__ whh, float* hbuf,
+                                                         const float* __restrict__ resid, float* __restrict__ y, int T, int* bar,
+                                                         int* err) {
+  __shared__ float hs[8 * (LSTM_SEG + 1)];   // h_{t-1}, segment-major with one pad float per segment (bank spread)
+  __shared__ float gs[32];
+  const int tid = threadIdx.x;
+  const int row = tid >> 3, seg = tid & 7;
+  const int gate = row >> 3, unit = row & 7;
+  const int u0 = blockIdx.x * 8;
+  const int nwg = gridDim.x;
+  float w[LSTM_SEG];
+  {
+    const float* wr = whh + (int64_t)(gate * LSTM_H + u0 + unit) * LSTM_H + seg * LSTM_SEG;
+#pragma unroll
+    for (int j = 0; j < LSTM_SEG; j += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wr + j);
+      w[j] = v[0]; w[j + 1] = v[1]; w[j + 2] = v[2]; w[j + 3] = v[3];
+    }
+  }
+  float c = 0.f;                             // cell state of unit tid (threads 0..7)
+  bool dead = false;
+  for (int t = 0; t < T; ++t) {
+    // h_{t-1} -> LDS (zeros at t = 0)
+    if (tid < LSTM_H / 4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (t > 0) v = *reinterpret_cast<const f32x4*>(hbuf + (int64_t)(t - 1) * LSTM_H + tid * 4);
+      const int col = tid * 4, sg = col / LSTM_SEG, j = col % LSTM_SEG;
+      float* d = hs + sg * (LSTM_SEG + 1) + j;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+    float acc = 0.f;
+    const float* hp = hs + seg * (LSTM_SEG + 1);
+#pragma unroll
+    for (int j = 0; j < LSTM_SEG; ++j) acc = fmaf(w[j], hp[j], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (seg == 0) gs[row] = acc + gx[(int64_t)t * 4 * LSTM_H + gate * LSTM_H + u0 + unit];
+    __syncthreads();
+    if (tid < 8) {
+      const float gi = 1.f / (1.f + expf(-gs[tid])), gf = 1.f / (1.f + expf(-gs[8 + tid]));
+      const float gg = tanhf(gs[16 + tid]), go = 1.f / (1.f + expf(-gs[24 + tid]));
+      c = gf * c + gi * gg;
+      const float h = go * tanhf(c);
+      const int64_t o = (int64_t)t * LSTM_H + u0 + tid;
+      hbuf[o] = h;
+      if (y) y[o] = h + (resid ? resid[o] : 0.f);
+    }
+    if (t + 1 == T) break;                   // nobody reads h_{T-1} inside this launch
+    // grid barrier: every workgroup's slice of h_t is visible device-wide before anyone starts step t + 1
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();                                                        // release: the h_t stores above
+      __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const int target = (t + 1) * nwg;
+      int spins = 0;
+      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > LSTM_SPIN_CAP || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      gs[0] = dead ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (gs[0] != 0.f) return;                // a peer never arrived: every workgroup leaves, the host reports the error flag
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // acquire for every wave: drop stale cached h rows
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int v2a_elu_pad(const float* x, float* out, int64_t T, int32_t C, int32_t pad, int32_t reflect, int32_t act,
+                           v2a_stream_t stream) {
+  V2A_REQUIRE(x && out && x != out, "v2a_elu_pad: null / aliased pointer");
+  V2A_REQUIRE(T > 0 && C > 0 && C % 4 == 0 && pad >= 0 && (!reflect || pad < T), "v2a_elu_pad: T=%lld C=%d pad=%d", (long long)T, C, pad);
+  V2A_REQUIRE((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "v2a_elu_pad: 16-byte alignment");
+  const int64_t total = (T + pad) * (C / 4);
+  hipLaunchKernelGGL(elu_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, T, C / 4, pad,
+                     reflect, act);
+  return v2a_check_launch("v2a_elu_pad");
+}
+
+extern "C" int v2a_lstm_layer(const float* gates_x, const float* w_hh, float* h, const float* resid, float* y, int32_t T, int32_t H,
+                              int32_t* workspace, v2a_stream_t stream) {
+  V2A_REQUIRE(gates_x && w_hh && h && workspace, "v2a_lstm_layer: null pointer");
+  V2A_REQUIRE(H == LSTM_H, "v2a_lstm_layer: hidden size %d (built for %d: encodec_24khz, 16 * num_filters)", H, LSTM_H);
+  V2A_REQUIRE(T > 0 && (resid == nullptr || y != nullptr), "v2a_lstm_layer: T=%d / resid without y", T);
+  V2A_REQUIRE((((uintptr_t)gates_x | (uintptr_t)w_hh | (uintptr_t)h) & 15) == 0, "v2a_lstm_layer: 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(workspace, 0, 2 * sizeof(int32_t), s);      // [0] barrier counter, [1] error flag
+  if (e != hipSuccess) return v2a_fail(V2A_ERR_LAUNCH, "v2a_lstm_layer: memset: %s", hipGetErrorString(e));
+  // H/8 = 64 workgroups of 256 threads: co-resident on any free MI355X (256 CUs); a workgroup that never sees its peers
+  // gives up after LSTM_SPIN_CAP polls and raises workspace[1]
+  hipLaunchKernelGGL(lstm_layer_kernel, dim3(H / 8), dim3(256), 0, s, gates_x, w_hh, h, resid, y, T, workspace, workspace + 1);
+  return v2a_check_launch("v2a_lstm_layer");
+}

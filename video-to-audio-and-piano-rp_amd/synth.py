@@ -113,3 +113,29 @@ def synthetic_piano_frames(b: int, t: int, H: int = 100, W: int = 900, seed: int
             f += 0.03 * rs.standard_normal((H, W)).astype(np.float32)
             out[bi, 0, ti] = np.clip(f, 0.0, 1.0)
     return torch.from_numpy(out)
+
+
+def random_encodec_decoder_state_dict(seed: int = 0) -> dict[str, torch.Tensor]:
+    """Seeded weights in the key layout of `EncodecModel(EncodecConfig()).decoder.state_dict()` (weight_norm g / v pairs),
+    the facebook/encodec_24khz architecture the reference loads by name (x3:421-423; unreachable offline).  numpy
+    RandomState stream: same tensors on any machine.  Scales keep activations O(1) through the stack and the LSTM gates
+    out of saturation."""
+    import numpy as np
+
+    from .encodec import expected_state_dict_shapes
+
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for k, shp in expected_state_dict_shapes().items():
+        if k.endswith("original0"):
+            v = rs.uniform(0.8, 1.6, shp)
+        elif k.endswith("original1"):
+            v = rs.standard_normal(shp) / math.sqrt(shp[1] * shp[2])
+        elif "lstm.weight" in k:
+            v = rs.uniform(-1.0, 1.0, shp) / math.sqrt(shp[1])
+        elif "lstm.bias" in k:
+            v = rs.uniform(-0.1, 0.1, shp)
+        else:
+            v = 0.05 * rs.standard_normal(shp)
+        sd[k] = torch.from_numpy(v.astype(np.float32))
+    return sd
