@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the supplementary 8-clips-per-GPU measurement (N=1 only)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="grid points of the bounded CPU sample")
     ap.add_argument("--no-video2roll", action="store_true", help="skip the supplementary Video2Roll frame-encoder measurement (SURVEY 8f N2)")
+    ap.add_argument("--no-vocoder", action="store_true", help="skip the supplementary Encodec-decoder measurement (SURVEY 8f N1)")
     ap.add_argument("--video2roll-frames", type=int, default=251, help="video frames per clip: floor(750 / 3) + 1 (x3:1913)")
     args = ap.parse_args()
 
@@ -178,6 +179,9 @@ def main():
         if not args.no_video2roll:
             res["video2roll"] = video2roll_leg(L, args, dev, cpu=not args.no_cpu_baseline)
             log("video2roll leg done")
+        if not args.no_vocoder:
+            res["vocoder"] = vocoder_leg(L, args, dev, T, cpu=not args.no_cpu_baseline)
+            log("vocoder leg done")
         if not args.no_cpu_baseline:
             res.update(cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T))
     if rank == 0:
@@ -185,6 +189,54 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def vocoder_leg(L, args, dev, T, cpu=True):
+    """Supplementary: latents (1, 128, T) -> 24 kHz waveform through the Encodec decoder (SURVEY 8f N1, x3:434-437,
+    predict.py:277-278) -- downstream of the timed region of the headline metric, reported beside it.  fp32 throughout."""
+    from v2a_amd.encodec import EncodecDecoder
+    from v2a_amd.synth import random_encodec_decoder_state_dict
+    sd = random_encodec_decoder_state_dict(0)
+    dec = EncodecDecoder(sd, dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    emb = torch.randn(1, 128, T, generator=g).to(dev)
+    dec.decoder(emb)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        wav = dec.decoder(emb)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    assert wav.shape == (1, 1, 320 * T) and bool(torch.isfinite(wav).all())
+    prof = L.KernelProfiler()
+    L.set_profiler(prof)
+    dec.decoder(emb)
+    L.set_profiler(None)
+    agg = prof.summary()
+    tot_ms = sum(a["ms"] for a in agg.values())
+    kern = {}
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        e = {"launches": a["launches"], "ms": round(a["ms"], 3), "share": round(a["ms"] / tot_ms, 4)}
+        if a["flops"] > 0:
+            e["tflops"] = round(a["flops"] / a["ms"] / 1e9, 3)
+        else:
+            e["gbs"] = round(a["bytes"] / a["ms"] / 1e6, 1)
+        kern[k] = e
+    res = {"latent_frames": T, "samples": 320 * T, "ms_per_clip": round(el * 1e3, 2), "audio_seconds_per_s": round(320 * T / 24000 / el, 1),
+           "dtype": "fp32", "eager_kernel_ms": round(tot_ms, 2), "kernels": kern,
+           "note": "EncodecDecoder.decoder on random latents, seeded weights; outside the timed region of `value`"}
+    if cpu:
+        from oracle import encodec_oracle as EO
+        torch.set_num_threads(host_cores())
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref = EO.decoder_forward(sd, emb.cpu())
+            cel = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(320 * T / 24000 / cel, 2), "unit": "audio-seconds/s", "cores": host_cores(), "kind": "port",
+                               "sample": "the same clip through oracle/encodec_oracle.py (torch fp32)"}
+        res["parity_vs_cpu"] = {"max_abs": float((wav.cpu() - ref).abs().max())}
+    return res
 
 
 def video2roll_leg(L, args, dev, cpu=True):

@@ -277,8 +277,9 @@ int v2a_elu_pad(const float* x, float* out, int64_t T, int32_t C, int32_t pad, i
 /* One nn.LSTM layer's recurrence over T steps (batch 1, hidden H = 512, zero initial state), gates in torch order (i,f,g,o):
  *   g_t = gates_x[t] + W_hh h_{t-1};  c_t = sig(f) c_{t-1} + sig(i) tanh(g);  h_t = sig(o) tanh(c_t)
  * gates_x[t] = W_ih x_t + b_ih + b_hh comes from a v2a_gemm.  h (T, H) receives every h_t; with y != NULL also
- * y[t] = h_t + resid[t] (the skip of EncodecLSTM).  Persistent kernel of H/8 workgroups with W_hh in registers and a
- * counter barrier per step; workspace = 2 int32 (zeroed by the call; workspace[1] != 0 afterwards means a workgroup timed
+ * y[t] = h_t + resid[t] (the skip of EncodecLSTM).  Persistent kernel of H/8 workgroups with W_hh in registers; h_t travels
+ * between workgroups as 64-bit {value, step tag} words (device-scope atomic store / polled load), one round trip per step.
+ * workspace = 4*H + 2 int32, 8-byte aligned (zeroed by the call; workspace[4*H] != 0 afterwards means a workgroup timed
  * out waiting for its peers and the result is invalid). */
 int v2a_lstm_layer(const float* gates_x, const float* w_hh, float* h, const float* resid, float* y, int32_t T, int32_t H,
                    int32_t* workspace, v2a_stream_t stream);

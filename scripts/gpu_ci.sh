@@ -28,7 +28,7 @@ for s in "$@"; do
     bench_nocpu) run bench_nocpu 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_shapes) run bench_shapes 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --shapes ;;
     bench8) run bench8 600 python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline ;;
-    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph --no-batched --no-video2roll"
+    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph --no-batched --no-video2roll --no-vocoder"
          i=0
          for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
            i=$((i+1)); rm -rf /tmp/pmc$i
@@ -48,9 +48,9 @@ for s in "$@"; do
            TAILN=0 run big_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --clips-per-gpu 8
            echo "--- big $t B=8: $(grep -E 'timed' gpurun_out/big_$t.log)"
          done; unset V2A_GEMM_BIG ;;
-    prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll
+    prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder
           mkdir -p gpurun_out/prof; cp /tmp/prof/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_multistream.csv ;;
-    prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched --no-video2roll
+    prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched --no-video2roll --no-vocoder
           mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
     prof_v2r) rm -rf /tmp/profv; run prof_v2r 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profv -- python bench.py --steps 1 --warmup 0 --cfm-steps 4 --no-cpu-baseline --no-roofline --no-batched
           mkdir -p gpurun_out/prof; cp /tmp/profv/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_video2roll.csv ;;

@@ -102,13 +102,13 @@ def test_lstm_layer_matches_torch_lstm(L):
     with torch.no_grad():
         ref = lstm(x)[0][:, 0]
         gx = x[:, 0] @ lstm.weight_ih_l0.t() + lstm.bias_ih_l0 + lstm.bias_hh_l0
-    ws = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(4 * H + 2, dtype=torch.int32, device=DEV)
     for _ in range(2):
         h = torch.zeros(T, H, device=DEV)
         y = torch.zeros(T, H, device=DEV)
         L.lstm_layer(gx.to(DEV), lstm.weight_hh_l0.detach().to(DEV).contiguous(), h, ws, T=T, H=H, resid=x[:, 0].to(DEV).contiguous(), y=y)
         torch.cuda.synchronize()
-        assert ws.tolist()[1] == 0
+        assert ws.tolist()[4 * H] == 0
         torch.testing.assert_close(h.cpu(), ref, atol=2e-5, rtol=2e-5)
         torch.testing.assert_close(y.cpu(), ref + x[:, 0], atol=2e-5, rtol=2e-5)
     with pytest.raises(L.V2AError, match="hidden size"):

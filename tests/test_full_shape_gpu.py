@@ -54,6 +54,21 @@ def test_full_sample_steps4_fp32_vs_oracle(full):
                                       context_mask=f["cm"], drop_text_cond=False, drop_text_prompt=False)
     t = O.sway_grid(2)
     assert float((g0 - (f["y0"] + (t[1] - t[0]) * pc)).abs().max()) < 1e-4
+    # latents -> waveform through the HIP vocoder attached as `vocos` (predict.py:171-172, x3:2277-2289): 240 000 samples
+    from oracle import encodec_oracle as EO
+    from v2a_amd import EncodecDecoder
+    from v2a_amd.synth import random_encodec_decoder_state_dict
+    vsd = random_encodec_decoder_state_dict(7)
+    m.vocos = EncodecDecoder(vsd, "cuda")
+    audio = m.sample(torch.zeros(1, 750, 128), y0=f["y0"], text_embed=f["text"], context=f["ctx"], context_mask=f["cm"],
+                     frames_embed=f["roll"], **kw)
+    assert isinstance(audio, list) and len(audio) == 1 and audio[0].shape == (240000,)
+    with torch.no_grad():
+        wref = EO.decode(vsd, ref.transpose(1, 2))[0]
+    werr = float((audio[0].cpu() - wref).abs().max())
+    print(f"full-shape fp32 sample + vocoder: max |delta wav| = {werr:.3e} (|wav| max {float(wref.abs().max()):.2f})")
+    assert werr < 2e-3
+    m.vocos = None
     del m
 
 

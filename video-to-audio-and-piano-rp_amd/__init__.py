@@ -9,7 +9,10 @@ from .collate import collate_clips, ClipRequest  # noqa: F401
 from .dist import shard_range, gather_latents  # noqa: F401
 from .features import (feature_cache_path, save_clip_cache, load_clip_cache, resample_indices,  # noqa: F401
                        resample_clip_features, encode_video_cached)
+from .video2roll import Video2RollEngine  # noqa: F401
+from .encodec import EncodecDecoder  # noqa: F401
 from . import _lib  # noqa: F401
 
 __all__ = ["E2TTS", "DiTConfig", "DiTEngine", "PackedWeights", "collate_clips", "ClipRequest",
-           "shard_range", "gather_latents", "sway_grid", "lens_to_mask", "expected_state_dict_shapes", "NOTES"]
+           "shard_range", "gather_latents", "sway_grid", "lens_to_mask", "expected_state_dict_shapes", "NOTES",
+           "Video2RollEngine", "EncodecDecoder"]

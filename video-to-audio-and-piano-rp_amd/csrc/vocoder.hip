@@ -3,7 +3,7 @@
 // transposed convolutions: K = 2C, N = stride*Cout), so only two kernels live here:
 //   * elu_pad:    out[pad + t] = ELU(x[t]) with `pad` reflected (causal Conv1d) or zero (ConvTranspose1d) rows in front;
 //   * lstm_layer: the recurrence of one nn.LSTM layer as a persistent kernel -- W_hh stays in registers across all T steps,
-//                 the H/8 workgroups exchange h_t through global memory and meet at a counter barrier once per step.
+//                 the H/8 workgroups exchange h_t through tagged 64-bit words in global memory (no barrier, no fences).
 #include "v2a_common.h"
 
 namespace {
@@ -34,21 +34,25 @@ __global__ __launch_bounds__(256) void elu_pad_kernel(const float* __restrict__ 
 // gx[t][4H] = W_ih x_t + b_ih + b_hh (a GEMM done by the caller); gates in torch order (i, f, g, o).
 // Workgroup w owns hidden units [8w, 8w+8): 32 rows of W_hh (4 gates x 8 units), thread (row = tid >> 3, seg = tid & 7) keeps
 // the H/8 weights of its row segment in registers for the whole sequence.  Per step: h_{t-1} (H floats, written by all
-// workgroups) -> LDS, 64 FMAs per thread, 8-lane reduction, cell update by 8 threads, h_t -> global, grid barrier.
+// workgroups) -> LDS, 64 FMAs per thread, 8-lane reduction, cell update by 8 threads, h_t published.
+// Exchange without a barrier: every h value travels as one 64-bit word {h, tag = t + 1} written with a device-scope atomic
+// store into a double-buffered table; a consumer polls the words it needs until their tag says "step t", so a step costs one
+// store -> load round trip through the memory-side cache and no fences (the tag and the value arrive together).  Two
+// buffers suffice: a workgroup can only run two steps ahead of a peer after that peer has read the older buffer.
 constexpr int LSTM_H = 512;
 constexpr int LSTM_SEG = LSTM_H / 8;       // 64 columns per thread
-constexpr int LSTM_SPIN_CAP = 1 << 22;     // polls before a workgroup gives up (a missing peer must not hang the GPU)
+constexpr int LSTM_SPIN_CAP = 1 << 21;     // polls before a workgroup gives up (a missing peer must not hang the GPU)
 
-__global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ gx, const float* __restrict__ whh, float* hbuf,
-                                                         const float* __restrict__ resid, float* __restrict__ y, int T, int* bar,
-                                                         int* err) {
+__global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                         float* __restrict__ hout, const float* __restrict__ resid,
+                                                         float* __restrict__ y, int T, unsigned long long* ex /* [2][H] */, int* err) {
   __shared__ float hs[8 * (LSTM_SEG + 1)];   // h_{t-1}, segment-major with one pad float per segment (bank spread)
   __shared__ float gs[32];
+  __shared__ int dead;
   const int tid = threadIdx.x;
   const int row = tid >> 3, seg = tid & 7;
   const int gate = row >> 3, unit = row & 7;
   const int u0 = blockIdx.x * 8;
-  const int nwg = gridDim.x;
   float w[LSTM_SEG];
   {
     const float* wr = whh + (int64_t)(gate * LSTM_H + u0 + unit) * LSTM_H + seg * LSTM_SEG;
@@ -58,18 +62,41 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
       w[j] = v[0]; w[j + 1] = v[1]; w[j + 2] = v[2]; w[j + 3] = v[3];
     }
   }
+  if (tid == 0) dead = 0;
   float c = 0.f;                             // cell state of unit tid (threads 0..7)
-  bool dead = false;
   for (int t = 0; t < T; ++t) {
-    // h_{t-1} -> LDS (zeros at t = 0)
+    // operands that do not depend on h: issued first so their latency hides behind the wait for h_{t-1}
+    float gxv = 0.f, rv = 0.f;
+    if (seg == 0) gxv = gx[(int64_t)t * 4 * LSTM_H + gate * LSTM_H + u0 + unit];
+    if (tid < 8 && resid) rv = resid[(int64_t)t * LSTM_H + u0 + tid];
+    // h_{t-1} -> LDS (zeros at t = 0): thread j < H/4 polls its 4 words of buffer (t-1) & 1 until they carry tag t
     if (tid < LSTM_H / 4) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (t > 0) v = *reinterpret_cast<const f32x4*>(hbuf + (int64_t)(t - 1) * LSTM_H + tid * 4);
+      if (t > 0) {
+        const unsigned long long* src = ex + (size_t)((t - 1) & 1) * LSTM_H + tid * 4;
+        int spins = 0;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned long long q = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[e] = __uint_as_float((unsigned)q);
+            ok = ok && (int)(q >> 32) == t;
+          }
+          if (ok) break;
+          if (++spins > LSTM_SPIN_CAP || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dead = 1;
+            break;
+          }
+        }
+      }
       const int col = tid * 4, sg = col / LSTM_SEG, j = col % LSTM_SEG;
       float* d = hs + sg * (LSTM_SEG + 1) + j;
       d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     }
     __syncthreads();
+    if (dead) return;                        // a peer never published: every workgroup leaves, the host reports the error flag
     float acc = 0.f;
     const float* hp = hs + seg * (LSTM_SEG + 1);
 #pragma unroll
@@ -77,39 +104,21 @@ __global__ __launch_bounds__(256) void lstm_layer_kernel(const float* __restrict
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if (seg == 0) gs[row] = acc + gx[(int64_t)t * 4 * LSTM_H + gate * LSTM_H + u0 + unit];
+    if (seg == 0) gs[row] = acc + gxv;
     __syncthreads();
     if (tid < 8) {
       const float gi = 1.f / (1.f + expf(-gs[tid])), gf = 1.f / (1.f + expf(-gs[8 + tid]));
       const float gg = tanhf(gs[16 + tid]), go = 1.f / (1.f + expf(-gs[24 + tid]));
       c = gf * c + gi * gg;
       const float h = go * tanhf(c);
+      // publish {h_t, tag t + 1} first (the critical path of every peer), then the plain outputs
+      const unsigned long long word = ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__float_as_uint(h);
+      __hip_atomic_store(ex + (size_t)(t & 1) * LSTM_H + u0 + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int64_t o = (int64_t)t * LSTM_H + u0 + tid;
-      hbuf[o] = h;
-      if (y) y[o] = h + (resid ? resid[o] : 0.f);
+      hout[o] = h;
+      if (y) y[o] = h + rv;
     }
-    if (t + 1 == T) break;                   // nobody reads h_{T-1} inside this launch
-    // grid barrier: every workgroup's slice of h_t is visible device-wide before anyone starts step t + 1
-    __syncthreads();
-    if (tid == 0) {
-      __threadfence();                                                        // release: the h_t stores above
-      __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const int target = (t + 1) * nwg;
-      int spins = 0;
-      while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > LSTM_SPIN_CAP || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dead = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      gs[0] = dead ? 1.f : 0.f;
-    }
-    __syncthreads();
-    if (gs[0] != 0.f) return;                // a peer never arrived: every workgroup leaves, the host reports the error flag
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // acquire for every wave: drop stale cached h rows
-    __syncthreads();
+    // no barrier here: gs / hs are rewritten only after the next step's __syncthreads pair
   }
 }
 
@@ -131,12 +140,15 @@ extern "C" int v2a_lstm_layer(const float* gates_x, const float* w_hh, float* h,
   V2A_REQUIRE(gates_x && w_hh && h && workspace, "v2a_lstm_layer: null pointer");
   V2A_REQUIRE(H == LSTM_H, "v2a_lstm_layer: hidden size %d (built for %d: encodec_24khz, 16 * num_filters)", H, LSTM_H);
   V2A_REQUIRE(T > 0 && (resid == nullptr || y != nullptr), "v2a_lstm_layer: T=%d / resid without y", T);
-  V2A_REQUIRE((((uintptr_t)gates_x | (uintptr_t)w_hh | (uintptr_t)h) & 15) == 0, "v2a_lstm_layer: 16-byte alignment");
+  V2A_REQUIRE((((uintptr_t)gates_x | (uintptr_t)w_hh | (uintptr_t)h) & 15) == 0 && ((uintptr_t)workspace & 7) == 0,
+              "v2a_lstm_layer: alignment (16 bytes for tensors, 8 for the workspace)");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, 2 * sizeof(int32_t), s);      // [0] barrier counter, [1] error flag
+  // workspace: [0, 4H) int32 = the two {h, tag} exchange tables (tags must start at 0), [4H] = error flag
+  hipError_t e = hipMemsetAsync(workspace, 0, (4 * (size_t)H + 2) * sizeof(int32_t), s);
   if (e != hipSuccess) return v2a_fail(V2A_ERR_LAUNCH, "v2a_lstm_layer: memset: %s", hipGetErrorString(e));
-  // H/8 = 64 workgroups of 256 threads: co-resident on any free MI355X (256 CUs); a workgroup that never sees its peers
-  // gives up after LSTM_SPIN_CAP polls and raises workspace[1]
-  hipLaunchKernelGGL(lstm_layer_kernel, dim3(H / 8), dim3(256), 0, s, gates_x, w_hh, h, resid, y, T, workspace, workspace + 1);
+  // H/8 = 64 workgroups of 256 threads: co-resident on any free MI355X (256 CUs); a workgroup whose peers never publish
+  // gives up after LSTM_SPIN_CAP polls and raises the error flag
+  hipLaunchKernelGGL(lstm_layer_kernel, dim3(H / 8), dim3(256), 0, s, gates_x, w_hh, h, resid, y, T,
+                     reinterpret_cast<unsigned long long*>(workspace), workspace + 4 * H);
   return v2a_check_launch("v2a_lstm_layer");
 }

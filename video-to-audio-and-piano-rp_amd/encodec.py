@@ -110,7 +110,7 @@ class EncodecDecoder:
         for r in RATIOS:
             self.hop *= r
         self._bufs: dict = {}
-        self._ws = torch.zeros(4, dtype=torch.int32, device=dev)      # per LSTM layer: [barrier counter, error flag]
+        self._ws = torch.zeros(2, 4 * self.H + 2, dtype=torch.int32, device=dev)      # per LSTM layer: exchange tables + error flag
 
     def _buf(self, name, rows, C):
         key = (name, rows, C)
@@ -144,7 +144,7 @@ class EncodecDecoder:
             hl = self._buf(f"h{l}", T, H)
             last = l == len(self.lstm) - 1
             y = self._buf("lstm_out", T, H) if last else None
-            L.lstm_layer(gx, lw["whh"], hl, self._ws[2 * l:], T=T, H=H, resid=h0 if last else None, y=y)
+            L.lstm_layer(gx, lw["whh"], hl, self._ws[l], T=T, H=H, resid=h0 if last else None, y=y)
             inp = hl
         x = y
         if taps is not None:
@@ -177,8 +177,8 @@ class EncodecDecoder:
         out = torch.empty(emb.shape[0], 1, emb.shape[2] * self.hop, device=self.dev, dtype=torch.float32)
         for i in range(emb.shape[0]):
             out[i, 0].copy_(self._decode_one(emb[i], taps if i == 0 else None))
-            flags = self._ws.tolist()                                              # one host sync per clip
-            if flags[1] or flags[3]:
+            flags = self._ws[:, 4 * self.H].tolist()                               # one host sync per clip
+            if flags[0] or flags[1]:
                 raise L.V2AError("v2a_lstm_layer: a workgroup timed out at the step barrier (GPU oversubscribed?); result discarded")
         return out
 
