@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_abi_version_and_error_string(lib):
     L = lib.lib()
-    assert L.v2a_abi_version() == 1
+    assert L.v2a_abi_version() == 2
     g = lib.GemmArgs()
     g.nseg = 5
     assert L.v2a_gemm(ctypes.byref(g), None) == -1                 # V2A_ERR_ARG, before any HIP call
@@ -60,6 +60,39 @@ def test_struct_layout_matches_header(lib):
             names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*$", part.strip())[0])
     assert names == [f[0] for f in lib.GemmArgs._fields_]
     assert ctypes.sizeof(lib.GemmArgs) % 8 == 0
+
+
+def test_roll_head_struct_and_new_entry_points_validate_on_cpu(lib):
+    """N1 / N2 entry points: the ctypes mirror of v2a_roll_head_args follows the header; bad arguments are refused before
+    any HIP call (no GPU here)."""
+    src = open(os.path.join(ROOT, "include", "v2a_cfm.h")).read()
+    body = re.search(r"typedef struct v2a_roll_head_args \{(.*?)\} v2a_roll_head_args;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        for part in decl.strip().split(","):
+            part = part.strip()
+            if part:
+                names.append(re.findall(r"\*?\s*([A-Za-z_][A-Za-z0-9_]*)\s*$", part)[0])
+    assert names == [f[0] for f in lib.RollHeadArgs._fields_]
+    L = lib.lib()
+    assert L.v2a_im2col(16, 1, 4, 4, 8, 3, 3, 1, 1, 3, 4, 16, 128, 0, 0, 0, None) == -1
+    assert b"Ho/Wo" in L.v2a_last_error()
+    assert L.v2a_pool2d(16, 32, None, 1, 4, 4, 6, 2, 2, 0, 1, 2, 2, 0, 0, None) == -1
+    assert b"geometry" in L.v2a_last_error()
+    assert L.v2a_lstm_layer(16, 16, 16, None, None, 10, 256, 16, None) == -1
+    assert b"hidden size" in L.v2a_last_error()
+    assert L.v2a_elu_pad(16, 32, 4, 6, 0, 0, 1, None) == -1
+    assert b"v2a_elu_pad" in L.v2a_last_error()
+    a = lib.RollHeadArgs()
+    assert L.v2a_roll_head(ctypes.byref(a), None) == -1
+    assert b"null" in L.v2a_last_error()
+    g = lib.GemmArgs()
+    g.nseg, g.M, g.N, g.compute_dtype, g.a_dtype = 1, 64, 64, 0, 0
+    g.a[0], g.lda[0], g.ka[0], g.w, g.ldw, g.out, g.ldo = 4096, 64, 64, 8192, 64, 12288, 64
+    g.a_row_offset, g.a_ktile_offset = 16, 16
+    assert L.v2a_gemm(ctypes.byref(g), None) == -1
+    assert b"offset tables" in L.v2a_last_error()
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch):
