@@ -229,6 +229,17 @@ int v2a_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32
                int32_t pad, int32_t Ho, int32_t Wo, void* col, int64_t ldo, int32_t out_dtype, int32_t window_t,
                int32_t window_first, v2a_stream_t stream);
 
+/* First-layer operand of the implicit GEMM (bf16): one clip's frames (T, H, W) fp32 -> column patches
+ *   out[j][xo][y][e],  j < T + 4, xo < Wo, y < H + 2*pad, e < 16   (bf16; (T+4)*Wo*(H+2*pad)*16 elements)
+ *   = frame clamp(j - 2, 0, T - 1) at row y - pad, column stride*xo - pad + e; zero outside the image and for e >= kw.
+ * The 5-frame window i of x3:1531-1539 is frames j = i .. i+4 of this replicate-padded clip, and the kh x kw taps of output
+ * pixel (yo, xo) in channel c are the kh consecutive 16-element rows from out[i + c][xo][stride*yo]: with
+ *   a_row_offset[m]    = ((i*Wo + xo)*Hp + stride*yo) * 16
+ *   a_ktile_offset[kt] = (kt / g) * Wo*Hp*16 + (kt % g) * 64,   g = ceil(kh / 4) K tiles per channel (weights zero-padded)
+ * v2a_gemm computes conv1 (v2r:138, 11x11 / stride 2 / pad 4) without the patch matrix of v2a_im2col. */
+int v2a_frames_pack(const float* frames, void* out, int32_t T, int32_t H, int32_t W, int32_t kw, int32_t stride, int32_t pad,
+                    int32_t Wo, v2a_stream_t stream);
+
 /* NHWC fp32 pooling: mode 0 = max (padding acts as -inf; nn.MaxPool2d(3, 2, 1) v2r:141), mode 1 = average over the full
  * k*k window (nn.AvgPool2d(2, 2) / (3, 1), pad 0, v2r:22-23).  C % 4 == 0.  The input / output maps may be stored with a
  * zero border of in_border / out_border pixels (the implicit-GEMM layout of v2a_gemm's offset tables): only interiors are

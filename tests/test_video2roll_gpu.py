@@ -128,6 +128,43 @@ def test_gemm_relu_and_residual_relu(L, compute, N):
     assert (out >= 0).all()
 
 
+# ------------------------------------------------------------------------------- first layer as an implicit GEMM
+def test_frames_pack_and_offset_tables_give_the_first_layer(L):
+    """v2a_frames_pack + v2a_gemm offset tables == Conv2d(5, 64, 11, stride 2, pad 4) on the 5-frame clamped windows
+    (v2r:138, x3:1531-1539), bf16 operands."""
+    T, H, W, kh, stride, pad, co = 6, 20, 37, 11, 2, 4, 64
+    g = _g(21)
+    frames = torch.rand(T, H, W, generator=g)
+    w = (torch.randn(co, 5, kh, kh, generator=g) / (5 * kh * kh) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(co, generator=g)
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kh) // stride + 1
+    Hp = H + 2 * pad
+    packed = torch.full(((T + 4) * Wo * Hp * 16,), 3.0, dtype=torch.bfloat16, device=DEV)
+    L.frames_pack(frames.to(DEV), packed, T=T, H=H, W=W, kw=kh, stride=stride, pad=pad, Wo=Wo)
+    pk = packed.float().cpu().view(T + 4, Wo, Hp, 16)
+    fp = F.pad(frames.to(torch.bfloat16).float(), (pad, pad + 16, pad, pad))                    # zero border (+ slack on the right)
+    idx = (torch.arange(T + 4) - 2).clamp(0, T - 1)
+    for xo in (0, 1, Wo // 2, Wo - 1):
+        ref = fp[idx][:, :, stride * xo: stride * xo + 16].clone()
+        ref[:, :, kh:] = 0
+        assert torch.equal(pk[:, xo], ref)
+    win = VO.frame_windows(frames[None, None])                                                   # (T, 5, H, W)
+    ref = F.relu(F.conv2d(win.to(torch.bfloat16).float(), w.float(), bias, stride, pad))         # (T, co, Ho, Wo)
+    first, n, gk = 1, 4, 3
+    wq = torch.zeros(co, 5, gk * 4, 16, dtype=torch.bfloat16)
+    wq[:, :, :kh, :kh] = w
+    ni, yo, xo = torch.arange(first, first + n)[:, None, None], torch.arange(Ho)[None, :, None], torch.arange(Wo)[None, None, :]
+    a_row = (((ni * Wo + xo) * Hp + yo * stride) * 16).reshape(-1).int()
+    kt = torch.arange(5 * gk)
+    a_k = ((kt // gk) * (Wo * Hp * 16) + (kt % gk) * 64).int()
+    out = torch.empty(n * Ho * Wo, co, device=DEV)
+    K = 5 * gk * 64
+    L.gemm([(packed, K, K)], wq.reshape(co, K).contiguous().to(DEV), out, M=n * Ho * Wo, N=co, compute=L.BF16, bias=bias.to(DEV), relu=True,
+           ldo=co, a_row_offset=a_row.to(DEV), a_ktile_offset=a_k.to(DEV))
+    got = out.cpu().view(n, Ho, Wo, co).permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref[first:first + n], atol=2e-3, rtol=2e-3)
+
+
 # ------------------------------------------------------------------------------- implicit-GEMM convolution (offset tables)
 @pytest.mark.parametrize("geom", [(3, 1, 1), (3, 2, 1), (1, 2, 0), (1, 1, 1)])
 @pytest.mark.parametrize("cout", [64, 128])

@@ -67,7 +67,7 @@ EXPORTS = [
     "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
-    "v2a_im2col", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
+    "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
     "v2a_elu_pad", "v2a_lstm_layer",
 ]
 
@@ -103,6 +103,7 @@ def _declare(lib):
     lib.v2a_step_advance.argtypes = [vp, vp]
     lib.v2a_cast_bf16.argtypes = [vp, vp, i64, vp]
     lib.v2a_im2col.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, i32, i32, vp]
+    lib.v2a_frames_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.v2a_pool2d.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.v2a_roll_head.argtypes = [C.POINTER(RollHeadArgs), vp]
     lib.v2a_roll_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
@@ -318,6 +319,11 @@ def im2col(x, col, *, B, H, W, C_, kh, kw, stride, pad, Ho, Wo, ldo, window_t=0,
     _launch("im2col<%s>" % ("f32" if col.dtype == torch.float32 else "bf16"), 0.0, B * Ho * Wo * (4.0 * K + col.element_size() * ldo),
             lambda: lib().v2a_im2col(x.data_ptr(), B, H, W, C_, kh, kw, stride, pad, Ho, Wo, col.data_ptr(), ldo,
                                      dt_code(col.dtype), window_t, window_first, stream_ptr()))
+
+
+def frames_pack(frames, out, *, T, H, W, kw, stride, pad, Wo):
+    _launch("frames_pack", 0.0, 4.0 * T * H * W + 32.0 * (T + 4) * Wo * (H + 2 * pad),
+            lambda: lib().v2a_frames_pack(frames.data_ptr(), out.data_ptr(), T, H, W, kw, stride, pad, Wo, stream_ptr()))
 
 
 def pool2d(x, out, *, B, H, W, C_, k, stride, pad, mode, Ho, Wo, out_bf16=None, in_border=0, out_border=0):

@@ -75,6 +75,36 @@ __global__ __launch_bounds__(256) void im2col_window_kernel(const float* __restr
   store4<OutT>(col + m * ldo + k0, v);
 }
 
+// ---- first-layer operand for the implicit GEMM: column patches of the replicate-padded clip -----------------------------------
+// out[j][xo][y][e] (bf16) for j < T + 4 frames, xo < Wo, y < Hp = H + 2*pad, e < 16:
+//   frame clamp(j - 2, 0, T - 1), row y - pad, column stride*xo - pad + e   (zero outside the image and for e >= kw)
+// For output pixel (window i, yo, xo) and input channel c the kh x kw taps are then the kh consecutive 16-element rows
+// starting at out[i + c][xo][stride*yo]: K tiles of 64 elements are contiguous, so the LDS-DMA GEMM reads them through its
+// row / K-tile offset tables and the 28 MB-per-window patch matrix of v2a_im2col is never written.
+__global__ __launch_bounds__(256) void frames_pack_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t total, int T,
+                                                          int H, int W, int Wo, int Hp, int kw, int stride, int pad) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per (j, xo, y)
+  if (gid >= total) return;
+  const int y = (int)(gid % Hp);
+  int64_t t = gid / Hp;
+  const int xo = (int)(t % Wo);
+  const int j = (int)(t / Wo);
+  int f = j - 2;
+  f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+  const int yi = y - pad;
+  bf16x8 lo, hi;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int xi = xo * stride - pad + e;
+    float v = 0.f;
+    if (e < kw && yi >= 0 && yi < H && xi >= 0 && xi < W) v = x[((int64_t)f * H + yi) * W + xi];
+    if (e < 8) lo[e] = (bf16_t)v; else hi[e - 8] = (bf16_t)v;
+  }
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out + gid * 16);
+  dst[0] = lo;
+  dst[1] = hi;
+}
+
 // ---- pooling, NHWC fp32, one thread per (n, yo, xo, 4 channels) ---------------------------------------------------------
 template <bool MAX>
 __global__ __launch_bounds__(256) void pool2d_kernel(const float* __restrict__ x, float* __restrict__ out, bf16_t* __restrict__ out2,
@@ -243,6 +273,19 @@ extern "C" int v2a_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32
                          Ho, Wo, ldo);
   }
   return v2a_check_launch("v2a_im2col");
+}
+
+extern "C" int v2a_frames_pack(const float* frames, void* out, int32_t T, int32_t H, int32_t W, int32_t kw, int32_t stride, int32_t pad,
+                               int32_t Wo, v2a_stream_t stream) {
+  V2A_REQUIRE(frames && out, "v2a_frames_pack: null pointer");
+  V2A_REQUIRE(T > 0 && H > 0 && W > 0 && kw > 0 && kw <= 16 && stride > 0 && pad >= 0, "v2a_frames_pack: bad geometry (kw=%d)", kw);
+  V2A_REQUIRE(Wo == (W + 2 * pad - kw) / stride + 1, "v2a_frames_pack: Wo=%d does not match the convolution geometry", Wo);
+  V2A_REQUIRE(((uintptr_t)out & 15) == 0, "v2a_frames_pack: 16-byte alignment");
+  const int Hp = H + 2 * pad;
+  const int64_t total = (int64_t)(T + 4) * Wo * Hp;
+  hipLaunchKernelGGL(frames_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames, (bf16_t*)out,
+                     total, T, H, W, Wo, Hp, kw, stride, pad);
+  return v2a_check_launch("v2a_frames_pack");
 }
 
 extern "C" int v2a_pool2d(const float* x, float* out, void* out_bf16, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k,
