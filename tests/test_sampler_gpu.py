@@ -197,3 +197,22 @@ def test_plan_switching_and_graph_reuse(small):
     assert torch.equal(a, c)
     d = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], steps=7, **_kw(i), **kw)       # same plan key except S
     assert not torch.equal(a, d)
+
+
+def test_many_models_and_plans_keep_their_streams_apart(small):
+    """Regression: side streams used to come from torch's 32-entry stream pool, two per plan; after ~16 plans one aliased the
+    graph-capture stream and the next graph replay crashed in hipGraphLaunch.  Streams are now three per process."""
+    from v2a_amd.dit import process_streams
+    i = small["inp"]
+    kw = dict(cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True, steps=3)
+    st = process_streams("cuda")
+    assert len({s.cuda_stream for s in st}) == 3 and process_streams("cuda") is st
+    ref = None
+    for k in range(20):
+        m = make_model(small["cfg"], small["P"], "bf16")
+        a = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+        one = {kk: v[:1, :33] if kk in ("y0", "text", "roll") else v[:1] for kk, v in i.items()}
+        m.sample(torch.zeros(1, 33, 16), y0=one["y0"], **_kw(one), **kw)             # second plan on the same model
+        assert m.engine().plan["st"] is st[0] and m.engine().plan["sf"] is st[1]
+        ref = a if ref is None else ref
+        assert torch.equal(a, ref)

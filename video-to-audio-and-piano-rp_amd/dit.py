@@ -172,6 +172,24 @@ class PackedWeights:
             ly["a_attn2"].wk = ly["a_attn2"].wv = None
 
 
+_STREAMS: dict = {}
+
+
+def process_streams(dev):
+    """(text side stream, frames side stream, graph-capture stream) of a device, created ONCE per process.
+
+    torch hands out streams from a pool of 32 per device and wraps around: allocating two side streams per plan made a later
+    plan's side stream alias torch's graph-capture stream after ~16 plans, and replaying a graph captured that way crashed
+    inside hipGraphLaunch.  Three fixed, distinct streams for the whole process cannot alias."""
+    dev = torch.device(dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    s = _STREAMS.get(key)
+    if s is None:
+        s = _STREAMS[key] = tuple(torch.cuda.Stream(device=dev) for _ in range(3))
+        assert len({x.cuda_stream for x in s}) == 3
+    return s
+
+
 class DiTEngine:
     """One plan = fixed (Bt sequences, T frames, nc context tokens); all buffers preallocated."""
 
@@ -250,7 +268,7 @@ class DiTEngine:
         p["per_sample_t"] = False
         # side streams: text block l+1 and frames block l+1 run beside the audio block l (see forward())
         if self.dev.type == "cuda" and self.multi_stream:
-            p["st"], p["sf"] = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
+            p["st"], p["sf"], _ = process_streams(self.dev)
         self.plan = p
         return p
 

@@ -23,7 +23,7 @@ from typing import Callable
 import torch
 
 from . import _lib as L
-from .dit import DiTConfig, DiTEngine, NOTES
+from .dit import DiTConfig, DiTEngine, NOTES, process_streams
 
 _IncompatibleKeys = namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 _V2R_PREFIX = "video2roll_net."
@@ -451,7 +451,7 @@ class E2TTS:
             y.copy_(keep)
             p["step"].zero_()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=process_streams(self._device)[2]):
                 eng.euler_step(y, cfg_strength, apg)
             self._graphs = {key: g}          # one plan is live at a time; drop graphs of older plans
         for _ in range(S):
