@@ -120,12 +120,22 @@ def main():
     lens = torch.full((B,), T, dtype=torch.long)
     n_clips = B * world
 
+    trace = bool(os.environ.get("V2A_BENCH_TRACE"))      # per-phase wall times on stderr (debug aid; adds host syncs)
+
     def one_step(steps=cfm_steps):
+        ta = time.perf_counter()
         for _ in range(args.cascade):
             out = model.sample(cond, y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, lens=lens,
                                duration=lens, steps=steps, cfg_strength=args.cfg_strength, remove_parallel_component=False,
                                sway_sampling=True, return_raw_output=True)
-        return v2a_amd.gather_latents(out, n_clips, B)
+        if trace:
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+        res = v2a_amd.gather_latents(out, n_clips, B)
+        if trace:
+            torch.cuda.synchronize()
+            log("rank %d: sample %.1f ms, gather %.1f ms" % (rank, (tb - ta) * 1e3, (time.perf_counter() - tb) * 1e3))
+        return res
 
     log("model ready: %s, B=%d/GPU, %d-point grid" % (args.dtype, B, cfm_steps))
     for i in range(args.warmup):

@@ -26,8 +26,13 @@ def gather_latents(local: torch.Tensor, n_clips: int, per_rank: int) -> torch.Te
         return local[:n_clips]
     world = dist.get_world_size()
     T, C = local.shape[1:]
+    dev = local.device
+    if dist.get_backend() != "nccl" and local.is_cuda:
+        # gloo rehearsal of the N-rank path on GPUs (CPU collectives): stage through the host explicitly.  Handing gloo a
+        # CUDA tensor while hipGraph replays are still queued stalled for ~25 s per call when two ranks shared one device.
+        local = local.cpu()
     buf = torch.zeros(per_rank, T, C, dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
     out = torch.empty(world * per_rank, T, C, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, buf)
-    return out[:n_clips]
+    return out[:n_clips].to(dev)
