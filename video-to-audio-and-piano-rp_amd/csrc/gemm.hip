@@ -179,6 +179,8 @@ template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
   static constexpr bool GATE = ON && EPI == V2A_EPI_GATE_RESID;
   f32x4 rs[RES ? TM : 1][RES ? RPS : 1];
   f32x4 gt[GATE ? TM : 1][GATE ? RPS : 1];
+  static constexpr bool SCAT = RES && !GATE;   // offset tables come with STORE / RESID only (checked on the host)
+  int32_t ro[SCAT ? TM : 1][SCAT ? RPS : 1];  // out / resid row offsets when rows are scattered (o_rowoff)
   static constexpr bool ROPE = ON && EPI == V2A_EPI_STORE;
   f32x4 cs[ROPE ? TM : 1][ROPE ? RPS : 1];     // (cos, sin) of the two column pairs a lane rotates
   __device__ __forceinline__ void load(const GemmParams& p, int m_base, int n_base, int lane) {
@@ -200,15 +202,34 @@ template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
     if constexpr (RES) {
       const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
       const int n = n_base + c4;
+      // kernel arguments copied once: the loops below stay free of scalar re-loads and branches
+      const int M = p.M;
       const bool full = n + 3 < p.N;
+      const float* resid = p.resid + n;
+      const int64_t ldr = p.ldr;
+      const int32_t* orow = SCAT ? p.o_rowoff : nullptr;
+      // scattered rows (implicit-GEMM convolution): all row offsets are requested before the first residual row depends on one
+      if constexpr (SCAT) {
+        if (orow) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < RPS; ++q) {
+              int m = m_base + i * 16 + r0 + q * RPI;
+              m = m < M ? m : M - 1;
+              ro[i][q] = orow[m];
+            }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < RPS; ++q) {
           const int m = m_base + i * 16 + r0 + q * RPI;
-          if (m < p.M && full) {
-            const int64_t ro = p.o_rowoff ? (int64_t)p.o_rowoff[m] : (int64_t)m * p.ldr;
-            rs[i][q] = *reinterpret_cast<const f32x4*>(p.resid + ro + n);
+          if (m < M && full) {
+            int64_t off = (int64_t)m * ldr;
+            if constexpr (SCAT) { if (orow) off = ro[i][q]; }
+            rs[i][q] = *reinterpret_cast<const f32x4*>(resid + off);
             if constexpr (GATE) gt[i][q] = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
           }
         }
@@ -222,6 +243,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
   constexpr int LD = WN + 4;                   // 16-B aligned rows, <= 2-way write conflicts
   const int lr = lane & 15, lq = lane >> 4;
   OutT* out = reinterpret_cast<OutT*>(p.out);
+  // kernel arguments copied once (the slab loops below otherwise re-load them from the argument segment per row)
+  const int M = p.M;
+  const bool relu = p.relu != 0;
+  const int32_t* orow = p.o_rowoff;           // scattered rows (implicit-GEMM convolution into a bordered map) or null
+  const int64_t ldo = p.ldo, ldr = p.ldr, ldo2 = p.ldo2;
+  bf16_t* out2 = p.out2;
+  const float* resid = p.resid;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     // one 16-row slab of the wave tile at a time: the staging area of a workgroup is a few KB of one ring stage
@@ -273,10 +301,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
       for (int q = 0; q < 16 / RPI; ++q) {
         const int r = r0 + q * RPI;
         const int m = m_base + i * 16 + r;
-        if (m >= p.M || !full) continue;
-        const bool sc = p.o_rowoff != nullptr;          // scattered rows (implicit-GEMM convolution into a padded map)
-        const int64_t ro = sc ? (int64_t)p.o_rowoff[m] : 0;
-        const int64_t o_out = sc ? ro : (int64_t)m * p.ldo, o_res = sc ? ro : (int64_t)m * p.ldr, o_out2 = sc ? ro : (int64_t)m * p.ldo2;
+        if (m >= M || !full) continue;
+        int64_t o_out = (int64_t)m * ldo, o_res = (int64_t)m * ldr, o_out2 = (int64_t)m * ldo2;
+        if constexpr (EPI == V2A_EPI_STORE || EPI == V2A_EPI_RESID) {     // offset tables come with STORE / RESID only
+          if (orow) {
+            int64_t ro;
+            if constexpr (PF && EPI == V2A_EPI_RESID) ro = pf.ro[i][q];
+            else ro = orow[m];
+            o_out = o_res = o_out2 = ro;
+          }
+        }
         f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bv[e];
@@ -303,13 +337,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
             rs = pf.rs[i][q];
             if constexpr (EPI == V2A_EPI_GATE_RESID) gt = pf.gt[i][q];
           } else {
-            rs = *reinterpret_cast<const f32x4*>(p.resid + o_res + n);
+            rs = *reinterpret_cast<const f32x4*>(resid + o_res + n);
             if constexpr (EPI == V2A_EPI_GATE_RESID) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
         }
-        if (p.relu) {
+        if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
@@ -320,11 +354,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
           *reinterpret_cast<bf16x4*>(out + o_out + n) = o;
         } else {
           *reinterpret_cast<f32x4*>(out + o_out + n) = v;
-          if (p.out2) {
+          if (out2) {
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(p.out2 + o_out2 + n) = o;
+            *reinterpret_cast<bf16x4*>(out2 + o_out2 + n) = o;
           }
         }
       }
