@@ -593,6 +593,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   int cur_seg = 0;
   set_offsets(p.lda[0]);
   const char* wbase = reinterpret_cast<const char*>(p.w);
+  // K-tile offset table read through the constant address space: a scalar load (lgkmcnt).  As a plain global load inside
+  // the K loop it became a VECTOR load (the LDS-DMA stores "clobber" memory for the compiler) followed by s_waitcnt vmcnt(0)
+  // -- on the dense path too, at the join of the two branches -- which drained the staged tiles in flight every K tile.
+  typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
+  const const_i32_ptr koff_tab = (const_i32_ptr)p.a_koff;
 
   auto issue = [&](int kt, int stage) {
     const int k0 = kt * 64;
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
       cur_seg = sgi;
       set_offsets(p.lda[sgi]);
     }
-    const int64_t akoff = p.a_koff ? (int64_t)p.a_koff[kt] : (int64_t)(k0 - kbeg);       // wave-uniform (scalar load)
+    const int64_t akoff = koff_tab ? (int64_t)koff_tab[kt] : (int64_t)(k0 - kbeg);       // wave-uniform (scalar load)
     const char* ab = reinterpret_cast<const char*>(p.a[sgi]) + akoff * 2;
     const char* wb = wbase + (int64_t)k0 * 2;
     char* st = smem_raw + stage * STAGE_BYTES;
