@@ -624,7 +624,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     }
   };
 
-  constexpr bool PF = BM * BN <= 128 * 256;   // the 256x256 tile has no registers to spare (128 accumulators per lane)
+  // epilogue operands are prefetched unless registers are short: the 256x256 tile (128 accumulators per lane) and the
+  // 8-wave 128x256 tile with BOTH residual and gate rows (64 + 64 registers on top of two fragment sets)
+  constexpr bool PF = BM * BN <= 128 * 256 && !(EPI == V2A_EPI_GATE_RESID && BM * BN == 128 * 256);
   EpiPrefetch<EPI, TM, WN, PF> pf;
   if (p.vec_epi) pf.load(p, m0 + wm * WM, n0 + wn * WN, lane);
   const int nk = p.K / 64;
@@ -643,24 +645,40 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     if (kt + NST - 1 < nk) issue(kt + NST - 1, (STAGE + NST - 1) % NST);
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
     const bf16_t* Ws = As + BM * 64;
+    // both 32-wide K halves of the tile are requested before the first MFMA: the second half's LDS latency runs under the
+    // first half's MFMA cluster instead of being exposed (the compiler otherwise emits read / wait / MFMA per half)
+    bf16x8 af[2][TM], bf[2][TN];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * WM + i * 16 + lr;
-        af[i] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WN + j * 16 + lr;
-        bf[j] = *reinterpret_cast<const bf16x8*>(Ws + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+        bf[kk][j] = *reinterpret_cast<const bf16x8*>(Ws + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
       }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+    // pin that order (the scheduler otherwise sinks the second half's reads back below the first MFMA cluster):
+    // [first half's reads] then {a few MFMAs, one read of the second half} ... then the remaining MFMAs
+    {
+      constexpr int NL = TM + TN, NM = TM * TN, PER = NM / NL > 0 ? NM / NL : 1;
+      __builtin_amdgcn_sched_group_barrier(0x100, NL, 0);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - PER * NL, 0);
     }
   };
   for (int kt = 0; kt < nk; kt += NST) {
