@@ -160,3 +160,19 @@ def test_batch_and_legacy_weight_names(params, dec):
     assert torch.equal(again, both)
     with pytest.raises(ValueError, match="7 latent frames"):
         dec.decoder(torch.zeros(1, 128, 5))
+
+
+def test_shortest_clip_and_sample_level_causality(params, dec):
+    """7 latent frames (the minimum the k=7 reflect padding allows); and causality end to end: changing latent frame 20
+    leaves the first 19 * 320 samples bit-identical (every conv pads on the left only, the LSTM runs forward)."""
+    emb = latents(7, 9)
+    with torch.no_grad():
+        ref = EO.decoder_forward(params, emb)
+    got = dec.decoder(emb)
+    assert got.shape == (1, 1, 7 * 320) and float((got.cpu() - ref).abs().max()) < 1e-4
+    x = latents(24, 3)
+    y = x.clone()
+    y[:, :, 20:] += 1.0
+    a, b = dec.decoder(x)[0, 0], dec.decoder(y)[0, 0]
+    assert torch.equal(a[: 19 * 320], b[: 19 * 320])
+    assert float((a[20 * 320:] - b[20 * 320:]).abs().max()) > 1e-3

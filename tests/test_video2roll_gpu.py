@@ -352,3 +352,23 @@ def test_sample_takes_frames_through_the_hip_encoder(small, params):
     print(f"\nV2P sample(frames=) fp32 vs CPU restatement: max |d| = {err:.3e}")
     assert err < 1e-3
     np.testing.assert_allclose(m.encode_frames(x, 40).cpu().numpy(), roll.numpy(), atol=1e-4)
+
+
+def test_inconsistent_pyramid_is_refused(engines):
+    """A frame size whose FTB maps do not line up with layer4's (the reference would fail inside FRB's torch.cat): raised
+    loudly before the head runs."""
+    from v2a_amd import _lib
+    x = torch.rand(1, 5, 90, 300, generator=_g(1))
+    with pytest.raises(_lib.V2AError, match="pyramid maps disagree"):
+        engines["bf16"].forward_windows(x)
+
+
+def test_other_consistent_frame_size(params, engines):
+    """The network is fully convolutional: a smaller frame whose pyramid lines up (40 x 132) matches the restatement too."""
+    x = torch.rand(2, 5, 40, 132, generator=_g(2))
+    with torch.no_grad():
+        ref = VO.resnet_forward(params, x)
+    got = engines["fp32"].forward_windows(x).cpu()
+    assert float((got - ref).abs().max()) < 2e-3
+    gb = engines["bf16"].forward_windows(x).cpu()
+    assert float((gb - ref).abs().max()) < 0.5
