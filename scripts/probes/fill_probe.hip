@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -85,8 +86,9 @@ template <typename F> float time_ms(F launch, int reps) {
   return ms / reps;
 }
 
-int main() {
-  const int rows = 1564, K = 1024, iters = 512;
+int main(int argc, char** argv) {
+  const int rows = 1564, K = argc > 1 ? atoi(argv[1]) : 1024, iters = 512;
+  printf("panel %d x %d bf16 = %.1f MB\n", rows, K, rows * (double)K * 2 / 1e6);
   char* panel; float* sink;
   hipMalloc(&panel, (size_t)rows * K * 2 + 4096);
   hipMemset(panel, 0, (size_t)rows * K * 2 + 4096);

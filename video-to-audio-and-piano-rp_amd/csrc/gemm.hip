@@ -42,6 +42,7 @@ struct GemmParams {
   const int32_t* a_rowoff;
   const int32_t* a_koff;
   const int32_t* o_rowoff;
+  int32_t krot;     // start each M band's K walk at a different K tile (see the kernel)
 };
 
 template <typename T> struct TileCfg;
@@ -599,7 +600,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
   const const_i32_ptr koff_tab = (const_i32_ptr)p.a_koff;
 
-  auto issue = [&](int kt, int stage) {
+  // K rotation: the tiles_m workgroups that share a W panel start their K walk at different K tiles and wrap around.  All of
+  // them walking k = 0, 1, 2 ... together made every K step a first touch of the same W lines -- one HBM round trip per step
+  // for the whole group -- whereas staggered starts pull the panel into L2 from tiles_m places at once and most steps of a
+  // workgroup then hit lines a neighbour already fetched.  (Changes only the fp32 summation order, identically in every run.)
+  const int nk_all = p.K / 64;
+  const int rot = p.krot ? (int)(((int64_t)tm * nk_all) / tiles_m) : 0;
+  auto issue = [&](int kt_seq, int stage) {
+    int kt = kt_seq + rot;
+    kt -= kt >= nk_all ? nk_all : 0;
     const int k0 = kt * 64;
     int sgi = 0, kbeg = 0;
     if (p.nseg > 1 && k0 >= p.kend[0]) { sgi = 1; kbeg = p.kend[0]; }
@@ -789,6 +798,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     p.vec_epi = ok ? 1 : 0;
   }
   p.relu = a->relu;
+  static const int krot = getenv("V2A_GEMM_KROT") ? atoi(getenv("V2A_GEMM_KROT")) : 1;   // on; V2A_GEMM_KROT=0 is the A/B tuning aid
+  p.krot = krot;
   p.a_rowoff = a->a_row_offset;
   p.a_koff = a->a_ktile_offset;
   p.o_rowoff = a->out_row_offset;
