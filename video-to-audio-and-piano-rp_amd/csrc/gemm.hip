@@ -798,7 +798,9 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     p.vec_epi = ok ? 1 : 0;
   }
   p.relu = a->relu;
-  static const int krot = getenv("V2A_GEMM_KROT") ? atoi(getenv("V2A_GEMM_KROT")) : 1;   // on; V2A_GEMM_KROT=0 is the A/B tuning aid
+  // off by default: +0.7 % throughput, but the fp32 summation order of a row then depends on how many rows the call has, so a
+  // clip's result would change (in the last bits) with the batch it is sampled in; V2A_GEMM_KROT=1 enables it
+  static const int krot = getenv("V2A_GEMM_KROT") ? atoi(getenv("V2A_GEMM_KROT")) : 0;
   p.krot = krot;
   p.a_rowoff = a->a_row_offset;
   p.a_koff = a->a_ktile_offset;
