@@ -72,3 +72,40 @@ def test_cli_scp_and_requests(tmp_path):
     dropped = cli.build_requests(items[:1], drop_prompt=True, n_frames=100)
     assert dropped[0].prompt == "" and dropped[0].n_frames == 100
     assert v2a_amd.collate_clips(dropped)[0][4] == [True]                              # video_drop_prompt
+
+
+# ---- piano-frame cache (V2P, x3:1876-1948) ------------------------------------------------------------------------------
+def test_piano_frame_indices_follow_the_reference_loop():
+    import math
+    import v2a_amd
+    n, dur, l = 240, 10.0, 750                         # 24 fps video, 10 s, 750 latent frames
+    idx = v2a_amd.piano_frame_indices(n, dur, l)
+    # the reference loop, literally (x3:1905-1911)
+    ref = []
+    fsv = int(3.0 * 320)
+    for i in range(0, int(dur * 24000) + fsv, fsv):
+        ref.append(min(round(i / 24000 / (dur / (n - 0))), n - 1))
+        if len(ref) >= math.floor(l / 3.0) + 1:
+            break
+    assert idx == ref and len(idx) == 251 and idx[0] == 0 and idx[-1] == n - 1
+    assert len(v2a_amd.piano_frame_indices(n, dur, 40)) == 14          # floor(40 / 3) + 1
+
+
+def test_load_piano_frames_batches_and_pads(tmp_path):
+    import v2a_amd
+    vids = [str(tmp_path / f"p{i}.mp4") for i in range(2)]
+    g = torch.Generator().manual_seed(1)
+    raws = [torch.rand(48, 100, 900, 1, generator=g), torch.rand(30, 100, 900, 1, generator=g)]
+    for v, r, d in zip(vids, raws, (2.0, 1.2)):
+        v2a_amd.save_piano_frames_cache(v2a_amd.piano_frames_cache_path(v), r, d)
+    assert v2a_amd.piano_frames_cache_path(vids[0]).endswith("p0.generated_frames_raw.2.npz")
+    fr = v2a_amd.load_piano_frames([vids[0], None, vids[1]], 150)
+    assert fr.shape == (3, 1, 51, 100, 900) and fr.dtype == torch.float32
+    assert torch.all(fr[1] == 0)                                        # missing video: zero frames
+    i0 = v2a_amd.piano_frame_indices(48, 2.0, 150)
+    assert torch.equal(fr[0, 0, : len(i0)], raws[0][i0, :, :, 0])
+    i1 = v2a_amd.piano_frame_indices(30, 1.2, 150)
+    assert len(i1) < 51 and torch.all(fr[2, 0, len(i1):] == 0)           # shorter clip: zero padding at the end
+    assert v2a_amd.load_piano_frames([None, None], 150) is None
+    with pytest.raises(FileNotFoundError):
+        v2a_amd.load_piano_frames([str(tmp_path / "nope.mp4")], 150)

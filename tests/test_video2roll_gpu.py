@@ -372,3 +372,45 @@ def test_other_consistent_frame_size(params, engines):
     assert float((got - ref).abs().max()) < 2e-3
     gb = engines["bf16"].forward_windows(x).cpu()
     assert float((gb - ref).abs().max()) < 0.5
+
+
+def test_cli_piano_to_waveform(tmp_path, params):
+    """The whole V2P chain from the command line (N4 + N2 + hot path + N1): scp list, cached CLIP / T5 / piano-frame files,
+    a reference-layout checkpoint that holds `video2roll_net.*`, Encodec weights -> latents AND 24 kHz wav files, equal to
+    composing the three stages by hand."""
+    import json
+    from scipy.io import wavfile
+    import v2a_amd
+    from v2a_amd import cli
+    from v2a_amd.synth import random_encodec_decoder_state_dict, random_state_dict, synthetic_piano_frames
+    mc = dict(dim=128, dim_text=192, dim_frames=64, depth=2, heads=2, dim_head=64, frames_heads=1, num_registers=4, max_seq_len=256,
+              num_channels=128)
+    cfg = v2a_amd.DiTConfig(**mc)
+    sd = random_state_dict(cfg, seed=3)
+    ck = tmp_path / "v2p.pt"
+    torch.save({"model_state_dict": {**sd, **{"video2roll_net." + k: v for k, v in params.items()}}}, ck)
+    esd = random_encodec_decoder_state_dict(5)
+    torch.save({"decoder." + k: v for k, v in esd.items()}, tmp_path / "encodec.pt")
+    vids = [str(tmp_path / f"piano{i}.mp4") for i in range(2)]
+    (tmp_path / "list.scp").write_text("".join(f"{v}\tpiano {i}\n" for i, v in enumerate(vids)))
+    g = torch.Generator().manual_seed(8)
+    for i, v in enumerate(vids):
+        dur = 0.5 + 0.02 * i
+        v2a_amd.save_clip_cache(v2a_amd.feature_cache_path(v), torch.randn(12 + i, cfg.dim_text, generator=g), dur)
+        np.savez(v.replace(".mp4", ".t5.npz"), (0.2 * torch.randn(4, cfg.dim, generator=g)).numpy())
+        v2a_amd.save_piano_frames_cache(v2a_amd.piano_frames_cache_path(v), synthetic_piano_frames(1, 12 + i, seed=i)[0, 0][..., None], dur)
+    out = tmp_path / "out"
+    written = cli.main([str(ck), "0", str(tmp_path / "list.scp"), "0", "2", str(out), "--batch", "2", "--steps", "3", "--frames", "40",
+                        "--dtype", "fp32", "--model-config", json.dumps(mc), "--piano", "--encodec", str(tmp_path / "encodec.pt")])
+    assert len(written) == 2
+    for i, v in enumerate(vids):
+        n = int((0.5 + 0.02 * i) * 24000) // 320
+        lat = np.load(out / f"piano{i}.latent.npy")
+        rate, wav = wavfile.read(out / f"piano{i}.wav")
+        assert rate == 24000 and wav.dtype == np.float32 and wav.shape == (n * 320,) and np.isfinite(wav).all()
+        ref = v2a_amd.EncodecDecoder(esd, DEV).decode(torch.from_numpy(lat[:n]).t()[None])[0].cpu().numpy()
+        np.testing.assert_allclose(wav, ref, atol=1e-5)
+    # the roll really conditioned the sample: without --piano the latents differ
+    plain = cli.main([str(ck), "0", str(tmp_path / "list.scp"), "0", "2", str(tmp_path / "out2"), "--batch", "2", "--steps", "3",
+                      "--frames", "40", "--dtype", "fp32", "--model-config", json.dumps(mc)])
+    assert np.abs(np.load(plain[0]) - np.load(written[0])).max() > 1e-3

@@ -8,7 +8,8 @@ from .e2tts import E2TTS, sway_grid, lens_to_mask, expected_state_dict_shapes  #
 from .collate import collate_clips, ClipRequest  # noqa: F401
 from .dist import shard_range, gather_latents  # noqa: F401
 from .features import (feature_cache_path, save_clip_cache, load_clip_cache, resample_indices,  # noqa: F401
-                       resample_clip_features, encode_video_cached)
+                       resample_clip_features, encode_video_cached, piano_frames_cache_path, save_piano_frames_cache,
+                       piano_frame_indices, load_piano_frames)
 from .video2roll import Video2RollEngine  # noqa: F401
 from .encodec import EncodecDecoder  # noqa: F401
 from . import _lib  # noqa: F401

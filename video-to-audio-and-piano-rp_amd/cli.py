@@ -9,8 +9,14 @@ under torchrun, sharded contiguously over the ranks with ONE all-gather of the l
 What it needs next to each video: the cached CLIP features `<video>.generated.npz` (features.py) and a cached
 FLAN-T5 context `<video>.t5.npz` (arr_0 = (nc, 1024) hidden states) unless `--t5 ./ckpts/flan-t5-large` points at
 local T5 weights.  Output: `<out_dir>/<name>.latent.npy`, the (n, 128) Encodec latent that the reference feeds to
-`vocos.decode` (src/inference_v2a.py / predict.py:277-278); the Encodec vocoder and the moviepy mux are outside
-this path.
+`vocos.decode` (src/inference_v2a.py / predict.py:277-278).
+
+  --piano            V2P (src/inference_v2p.py): the cached grey frames `<video>.generated_frames_raw.2.npz` (features.py) go
+                     through the HIP Video2Roll encoder; the checkpoint must hold `video2roll_net.*`
+  --encodec STATE    torch-saved state dict of `EncodecModel.from_pretrained("facebook/encodec_24khz")` (or of its decoder):
+                     each clip's valid frames are decoded by the HIP vocoder and written as `<name>.wav` (24 kHz float32),
+                     what the reference does with `save_to_filename` / torchaudio.save (x3:2291-2303, predict.py:279-281).
+The moviepy mux of audio and video stays outside (out of scope).
 """
 from __future__ import annotations
 
@@ -70,6 +76,8 @@ def main(argv=None):
     ap.add_argument("--t5", default=None, help="local FLAN-T5 directory (reference: ./ckpts/flan-t5-large)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model-config", default=None, help="JSON dict of transformer kwargs (default: predict.py:120-134)")
+    ap.add_argument("--piano", action="store_true", help="V2P: condition on the cached piano frames through the Video2Roll encoder")
+    ap.add_argument("--encodec", default=None, help="state dict (.pt) of the Encodec model / decoder: also write <name>.wav")
     a = ap.parse_args(argv)
 
     import torch.distributed as dist
@@ -98,6 +106,10 @@ def main(argv=None):
             b = tok([prompt], max_length=tok.model_max_length, padding=True, truncation=True, return_tensors="pt")
             with torch.no_grad():
                 return enc(input_ids=b.input_ids, attention_mask=b.attention_mask)[0][0]
+    vocoder = None
+    if a.encodec and rank == 0:
+        from .encodec import EncodecDecoder
+        vocoder = EncodecDecoder(torch.load(a.encodec, map_location="cpu"), torch.device("cuda", local))
     items = read_scp(a.test_scp, a.start, a.end)
     os.makedirs(a.out_dir, exist_ok=True)
     gen = torch.Generator().manual_seed(a.seed)
@@ -108,9 +120,13 @@ def main(argv=None):
         mine = chunk[s:e]
         if mine:
             batch8, extras = collate_clips(build_requests(mine, bool(a.drop_prompt), a.frames, t5_encode), channels, gen)
+            frames = None
+            if a.piano:
+                from .features import load_piano_frames
+                frames = load_piano_frames([vp for vp, _ in mine], int(batch8[3].max()))       # x3:1829, predict.py:231
             lat = model.sample(batch8[1], lens=batch8[3], duration=batch8[3], steps=a.steps, cfg_strength=a.cfg_strength,
                                remove_parallel_component=False, sway_sampling=True, video_drop_prompt=batch8[4],
-                               return_raw_output=True, **extras).to(torch.device("cuda", local))
+                               return_raw_output=True, frames=frames, **extras).to(torch.device("cuda", local))
         else:
             lat = torch.zeros(0, a.frames, channels, device=torch.device("cuda", local))
         if lat.shape[1] < a.frames:
@@ -122,6 +138,12 @@ def main(argv=None):
                 path = os.path.join(a.out_dir, name + ".latent.npy")
                 np.save(path, one.float().cpu().numpy())
                 written.append(path)
+                if vocoder is not None:
+                    from scipy.io import wavfile
+                    from .features import load_clip_cache, feature_cache_path
+                    n = min(a.frames, int(load_clip_cache(feature_cache_path(vp))[1] * 24000) // 320) if a.frames > 0 else one.shape[0]
+                    wav = vocoder.decode(one[:n].t()[None].float())[0]                     # predict.py:277-278
+                    wavfile.write(os.path.join(a.out_dir, name + ".wav"), 24000, wav.cpu().numpy())
     if world > 1:
         dist.destroy_process_group()
     return written

@@ -92,3 +92,63 @@ def encode_video_cached(video_paths, l: int, dim: int = 1280, video_encoder: str
         rows.append(resample_clip_features(emb.float(), duration, l, sampling_rate=sampling_rate, frame_size=frame_size,
                                            start_sample=start_sample, max_sample=max_sample))
     return torch.stack(rows, 0)
+
+
+# ---- piano-frame cache of the V2P path (the `piano` branch of E2TTS.encode_video_frames, x3:1829-1991) ------------------
+def piano_frames_cache_path(video_path: str) -> str:
+    """x3:1876: the grey 100x900 frames of a video are cached next to it."""
+    return video_path.replace(".mp4", ".generated_frames_raw.2.npz")
+
+
+def save_piano_frames_cache(path: str, frames_raw, duration: float) -> None:
+    """x3:1890-1891 `np.savez(frames_raw_path, frames_raw, duration)`: arr_0 = (n_video_frames, 100, 900, 1) float32 in
+    [0, 1] (ToTensor of the 'L' image), arr_1 = duration in seconds."""
+    fr = frames_raw.detach().cpu().numpy() if torch.is_tensor(frames_raw) else np.asarray(frames_raw)
+    np.savez(path, fr.astype(np.float32), duration)
+
+
+def piano_frame_indices(n_video_frames: int, duration: float, l: int, start_sample: int = 0, max_sample: int | None = None,
+                        video_multi: float = 3.0, sampling_rate: int = 24000, frame_size: int = 320) -> list[int]:
+    """x3:1903-1913: one video frame per `video_multi` latent frames (hop 3 * 320 samples), nearest by time, at most
+    floor(l / video_multi) + 1 of them.  The loop runs one hop past max_sample, as the reference's does."""
+    if max_sample is None:
+        max_sample = int(duration * sampling_rate)
+    hop = int(video_multi * frame_size)
+    out = []
+    for i in range(start_sample, max_sample + hop, hop):
+        out.append(min(round(i / sampling_rate / (duration / n_video_frames)), n_video_frames - 1))
+        if len(out) >= int(l // video_multi) + 1:
+            break
+    return out
+
+
+def load_piano_frames(video_paths, l: int) -> torch.Tensor | None:
+    """Batch form of the cached `piano` branch of encode_video_frames: (b, 1, t, 100, 900) float32 with
+    t = max(floor(l / 3) + 1, longest clip) and zero frames as padding (x3:1935-1948); `None` paths give all-zero clips
+    (x3:1939-1941).  Returns None when no path has frames (x3:1927-1928).  Tuples are (path, start_sample, max_sample)."""
+    clips, lens = [], []
+    for vp in video_paths:
+        if vp is None:
+            clips.append(None)
+            lens.append(0)
+            continue
+        start_sample, max_sample = 0, None
+        if isinstance(vp, tuple):
+            vp, start_sample, max_sample = vp
+        fp = piano_frames_cache_path(vp)
+        if not os.path.exists(fp):
+            raise FileNotFoundError(f"{fp}: no cached piano frames for {vp} (the reference decodes the video with moviepy here)")
+        data = np.load(fp)
+        raw = torch.from_numpy(data["arr_0"])
+        idx = piano_frame_indices(raw.shape[0], data["arr_1"].item(), l, start_sample, max_sample)
+        clips.append(raw[torch.tensor(idx)])
+        lens.append(len(idx))
+    if not any(c is not None for c in clips):
+        return None
+    H, W = next(c for c in clips if c is not None).shape[1:3]
+    t = max(int(l // 3.0) + 1, max(lens))
+    out = torch.zeros(len(clips), t, H, W, 1)
+    for i, c in enumerate(clips):
+        if c is not None:
+            out[i, : c.shape[0]] = c
+    return out.permute(0, 4, 1, 2, 3).contiguous()
