@@ -176,3 +176,23 @@ def test_shortest_clip_and_sample_level_causality(params, dec):
     a, b = dec.decoder(x)[0, 0], dec.decoder(y)[0, 0]
     assert torch.equal(a[: 19 * 320], b[: 19 * 320])
     assert float((a[20 * 320:] - b[20 * 320:]).abs().max()) > 1e-3
+
+
+def test_vocoder_next_to_other_work_on_the_gpu(dec, L):
+    """The LSTM kernel is persistent (64 workgroups exchanging h_t through memory): decoding while another stream keeps the
+    GPU busy with GEMMs must neither hang nor change a bit (workgroups that start late are simply waited for)."""
+    emb = latents(200, 4)
+    ref = dec.decoder(emb).clone()
+    M, N, K = 4096, 4096, 1024
+    a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    w = torch.randn(N, K, device=DEV).to(torch.bfloat16)
+    out = torch.empty(M, N, device=DEV)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(300):                                    # ~20 ms of back-to-back chip-filling GEMMs
+            L.gemm([(a, K, K)], w, out, M=M, N=N, compute=L.BF16)
+    got = [dec.decoder(emb).clone() for _ in range(3)]          # on the current stream, concurrently
+    torch.cuda.synchronize()
+    for g in got:
+        assert torch.equal(g, ref)
