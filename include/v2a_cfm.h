@@ -295,6 +295,14 @@ int v2a_elu_pad(const float* x, float* out, int64_t T, int32_t C, int32_t pad, i
 int v2a_lstm_layer(const float* gates_x, const float* w_hh, float* h, const float* resid, float* y, int32_t T, int32_t H,
                    int32_t* workspace, v2a_stream_t stream);
 
+/* Both layers of EncodecLSTM (2-layer nn.LSTM + skip, batch 1, H = 512) in one persistent kernel: pipeline step s runs layer 0
+ * at time s and layer 1 at time s - 1, both fed by values published in step s - 1, so the sequence costs T + 1 exchange round
+ * trips instead of 2T and layer 1's input projection (w_ih1, bias1 = b_ih1 + b_hh1) is done in the kernel.
+ *   y[t] = h1[t] + resid[t]   (resid may be NULL).   gates_x0[t] = W_ih0 x_t + b_ih0 + b_hh0 from a v2a_gemm.
+ * workspace = 8*H + 2 int32, 8-byte aligned (zeroed by the call; workspace[8*H] != 0 afterwards = a workgroup timed out). */
+int v2a_lstm2(const float* gates_x0, const float* w_hh0, const float* w_ih1, const float* bias1, const float* w_hh1,
+              const float* resid, float* y, int32_t T, int32_t H, int32_t* workspace, v2a_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

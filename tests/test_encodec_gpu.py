@@ -196,3 +196,25 @@ def test_vocoder_next_to_other_work_on_the_gpu(dec, L):
     torch.cuda.synchronize()
     for g in got:
         assert torch.equal(g, ref)
+
+
+def test_lstm2_matches_torch_two_layer_lstm(L):
+    """Both layers in one persistent kernel (layer 1 one step behind layer 0) == nn.LSTM(512, 512, 2) + skip, 300 steps."""
+    T, H = 300, 512
+    lstm = torch.nn.LSTM(H, H, 2)
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.copy_(torch.rand(p.shape, generator=_g(p.numel() + 1)) * 2 - 1).mul_(1 / H ** 0.5)
+    x = torch.randn(T, 1, H, generator=_g(2))
+    with torch.no_grad():
+        ref = lstm(x)[0][:, 0] + x[:, 0]
+        gx = x[:, 0] @ lstm.weight_ih_l0.t() + lstm.bias_ih_l0 + lstm.bias_hh_l0
+    d = lambda t: t.detach().to(DEV).contiguous()
+    ws = torch.zeros(8 * H + 2, dtype=torch.int32, device=DEV)
+    for _ in range(2):                                           # the second call re-arms the exchange tables
+        y = torch.zeros(T, H, device=DEV)
+        L.lstm2(d(gx), d(lstm.weight_hh_l0), d(lstm.weight_ih_l1), d(lstm.bias_ih_l1 + lstm.bias_hh_l1), d(lstm.weight_hh_l1), y, ws,
+                T=T, H=H, resid=d(x[:, 0]))
+        torch.cuda.synchronize()
+        assert ws.tolist()[8 * H] == 0
+        torch.testing.assert_close(y.cpu(), ref, atol=3e-5, rtol=3e-5)

@@ -68,7 +68,7 @@ EXPORTS = [
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
     "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
-    "v2a_elu_pad", "v2a_lstm_layer",
+    "v2a_elu_pad", "v2a_lstm_layer", "v2a_lstm2",
 ]
 
 
@@ -109,6 +109,7 @@ def _declare(lib):
     lib.v2a_roll_expand.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     lib.v2a_elu_pad.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp]
     lib.v2a_lstm_layer.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.v2a_lstm2.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     for name in EXPORTS:
         if name not in ("v2a_abi_version", "v2a_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -350,3 +351,9 @@ def lstm_layer(gates_x, w_hh, h, workspace, *, T, H, resid=None, y=None):
     _launch("lstm_layer", 2.0 * T * 4 * H * H, 4.0 * T * 6 * H,
             lambda: lib().v2a_lstm_layer(gates_x.data_ptr(), w_hh.data_ptr(), h.data_ptr(), _p(resid), _p(y), T, H,
                                          workspace.data_ptr(), stream_ptr()))
+
+
+def lstm2(gates_x0, w_hh0, w_ih1, bias1, w_hh1, y, workspace, *, T, H, resid=None):
+    _launch("lstm2", 2.0 * T * 4 * H * H * 3, 4.0 * T * 6 * H,
+            lambda: lib().v2a_lstm2(gates_x0.data_ptr(), w_hh0.data_ptr(), w_ih1.data_ptr(), bias1.data_ptr(), w_hh1.data_ptr(),
+                                    _p(resid), y.data_ptr(), T, H, workspace.data_ptr(), stream_ptr()))

@@ -10,7 +10,7 @@ Design: activations are time-major [T][C] fp32.  A causal Conv1d(k) is then ONE 
 (lda = C, K = k*C) over a buffer with k-1 reflected rows in front; a ConvTranspose1d(k = 2r, stride r) is ONE `v2a_gemm`
 with A row q = [x[q-1], x[q]] (K = 2C) and N = r*Cout columns ordered (phase, channel), whose [L][r*Cout] output is the
 up-sampled [L*r][Cout] signal in place -- no col2im, no scatter.  `v2a_elu_pad` applies ELU and writes the pad rows in one
-pass; `v2a_lstm_layer` runs each LSTM layer's recurrence as a persistent kernel with W_hh in registers.  Weight norm is
+pass; `v2a_lstm2` runs both LSTM layers' recurrences in one persistent kernel (weights in registers, T + 1 exchange steps).  Weight norm is
 resolved at load time.  Everything is fp32 (exact-fp32 MFMA): the whole decoder is ~30 GFLOP, memory- and latency-bound.
 There is no CPU fallback: without libv2a_cfm.so every call raises.
 """
@@ -110,7 +110,7 @@ class EncodecDecoder:
         for r in RATIOS:
             self.hop *= r
         self._bufs: dict = {}
-        self._ws = torch.zeros(2, 4 * self.H + 2, dtype=torch.int32, device=dev)      # per LSTM layer: exchange tables + error flag
+        self._ws = torch.zeros(8 * self.H + 2, dtype=torch.int32, device=dev)      # exchange tables of both LSTM layers + error flag
 
     def _buf(self, name, rows, C):
         key = (name, rows, C)
@@ -137,16 +137,12 @@ class EncodecDecoder:
         H = self.H
         x0 = emb.t().contiguous()                                                  # time-major (T, 128)
         h0 = self._conv(self.c0, x0, T, "c0", act=False)
-        inp = h0
-        for l, lw in enumerate(self.lstm):
-            gx = self._buf(f"gx{l}", T, 4 * H)
-            L.gemm([(inp, H, H)], lw["wih"], gx, M=T, N=4 * H, compute=L.F32, bias=lw["b"], ldo=4 * H)
-            hl = self._buf(f"h{l}", T, H)
-            last = l == len(self.lstm) - 1
-            y = self._buf("lstm_out", T, H) if last else None
-            L.lstm_layer(gx, lw["whh"], hl, self._ws[l], T=T, H=H, resid=h0 if last else None, y=y)
-            inp = hl
-        x = y
+        # 2-layer LSTM + skip: one GEMM for layer 0's input projection, then both recurrences in one persistent kernel
+        l0, l1 = self.lstm
+        gx = self._buf("gx0", T, 4 * H)
+        L.gemm([(h0, H, H)], l0["wih"], gx, M=T, N=4 * H, compute=L.F32, bias=l0["b"], ldo=4 * H)
+        x = self._buf("lstm_out", T, H)
+        L.lstm2(gx, l0["whh"], l1["wih"], l1["b"], l1["whh"], x, self._ws, T=T, H=H, resid=h0)
         if taps is not None:
             taps["lstm"] = x.t().clone()
         Lc, C = T, H
@@ -177,9 +173,8 @@ class EncodecDecoder:
         out = torch.empty(emb.shape[0], 1, emb.shape[2] * self.hop, device=self.dev, dtype=torch.float32)
         for i in range(emb.shape[0]):
             out[i, 0].copy_(self._decode_one(emb[i], taps if i == 0 else None))
-            flags = self._ws[:, 4 * self.H].tolist()                               # one host sync per clip
-            if flags[0] or flags[1]:
-                raise L.V2AError("v2a_lstm_layer: a workgroup timed out at the step barrier (GPU oversubscribed?); result discarded")
+            if int(self._ws[8 * self.H].item()):                                   # one host sync per clip
+                raise L.V2AError("v2a_lstm2: a workgroup timed out at the step barrier (GPU oversubscribed?); result discarded")
         return out
 
     def decode(self, emb):
