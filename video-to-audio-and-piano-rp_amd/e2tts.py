@@ -451,7 +451,9 @@ class E2TTS:
             y.copy_(keep)
             p["step"].zero_()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=process_streams(self._device)[2]):
+            # thread-local capture mode: only this thread's calls are policed, so a communication library's watchdog thread
+            # (RCCL under torch.distributed) polling its events meanwhile cannot invalidate the capture
+            with torch.cuda.graph(g, stream=process_streams(self._device)[2], capture_error_mode="thread_local"):
                 eng.euler_step(y, cfg_strength, apg)
             self._graphs = {key: g}          # one plan is live at a time; drop graphs of older plans
         for _ in range(S):
