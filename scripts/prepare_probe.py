@@ -48,3 +48,18 @@ for _ in range(N):
 torch.cuda.synchronize()
 tot = (time.perf_counter() - t0) / N * 1e3
 print(f"sample {tot:.2f} ms = prepare {acc['prepare'] / N * 1e3:.2f} + euler loop {acc['run'] / N * 1e3:.2f} + rest {tot - (acc['prepare'] + acc['run']) / N * 1e3:.2f}")
+
+# ---- is the Euler loop bound by the host enqueueing the graph, or by the GPU executing it? ----
+eng.prepare, model._run_steps = orig_prepare, orig_run
+model.sample(cond, **kw)
+torch.cuda.synchronize()
+g = next(iter(model._graphs.values()))
+for reps in (1, 31):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"{reps:2d} replay(s): host enqueue {t_host * 1e3 / reps:.3f} ms per replay, until the GPU is done {t_all * 1e3 / reps:.3f} ms per replay")
