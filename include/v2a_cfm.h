@@ -9,8 +9,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name says `host`;
- *   - no allocation, no synchronisation, no global state inside: the caller owns every
- *     buffer and passes the stream; all launches are graph-capturable;
+ *   - no allocation and no synchronisation inside: the caller owns every buffer and passes
+ *     the stream; all launches are graph-capturable.  The only process-wide state is the
+ *     explicit tile-selection override of v2a_set_tuning() (benchmarking aid, defaults =
+ *     automatic) and per-kernel "large LDS" attributes set once, thread-safely, at the first
+ *     launch of each kernel; nothing is read from the environment;
  *   - return value 0 = ok, negative = error; v2a_last_error() gives the message of the
  *     last failing call on the calling thread;
  *   - "compute dtype" T is V2A_F32 (parity mode, exact-fp32 MFMA) or V2A_BF16 (bf16
@@ -39,7 +42,7 @@ enum {
   V2A_ERR_LAUNCH = -2  /* hipGetLastError() after launch */
 };
 
-int v2a_abi_version(void);
+int v2a_abi_version(void);        /* 3 */
 const char* v2a_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -103,6 +106,19 @@ typedef struct v2a_gemm_args {
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
+/* sizeof(v2a_gemm_args) as the library was built: a binding checks its mirror of the struct against this */
+int v2a_gemm_args_size(void);
+
+/* Tile-selection overrides of v2a_gemm for A/B measurements (bench.py, scripts/): every field 0 / -1 = automatic.
+ * Process-wide; call it between launches, not concurrently with them.  NULL restores the defaults. */
+typedef struct v2a_tuning {
+  int32_t gemm_force_tile;        /* -1 = by shape; 0..5 = one LDS-DMA tile shape for every bf16 x bf16 GEMM, 6 = the 256x256 8-phase kernel */
+  int32_t gemm_k_rotation;        /* 1: M bands that share a W panel start their K walk at different K tiles (changes fp32 summation order with M) */
+  int32_t gemm_8phase;            /* 256x256 phase-interleaved kernel for wide outputs (N >= 2048): 0 off, 1 on (staggered wave rows), 2 on (lock-step) */
+  int32_t gemm_8phase_min_tiles;  /* ... when the problem yields at least this many 256x256 tiles (0 = 64) */
+  int32_t reserved[4];
+} v2a_tuning;
+int v2a_set_tuning(const v2a_tuning* tuning);
 
 /* ---------------------------------------------------------------------------------------
  * RMSNorm / AdaptiveRMSNorm:  y = x / max(|x|_2, 1e-12) * sqrt(d) * gamma

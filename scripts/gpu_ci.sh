@@ -15,13 +15,16 @@ run() {  # name timeout cmd...
 }
 for s in "$@"; do
   case $s in
+    k8p) run k8p 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "8phase" ;;
+    probe) TAILN=40 run probe 600 python scripts/gemm_probe.py ${PROBE_ARGS:-} ;;
+    probe_geglu) TAILN=40 run probe_geglu 600 python scripts/gemm_probe.py --epi geglu 1564x8192x1024 1564x10240x1280 1564x4096x512 12512x8192x1024 ;;
     kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x --tb=short ;;
     kernels_all) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=line ;;
     sampler) run sampler 600 python -m pytest tests/test_sampler_gpu.py -q -m gpu -x --tb=short -s ;;
     sampler_all) run sampler 600 python -m pytest tests/test_sampler_gpu.py -q -m gpu --tb=short -s ;;
     v2r) run v2r 600 python -m pytest tests/test_video2roll_gpu.py -q -m gpu -x --tb=short -s ;;
     enc) run enc 600 python -m pytest tests/test_encodec_gpu.py -q -m gpu -x --tb=short -s ;;
-    full) run full 900 python -m pytest tests/test_full_shape_gpu.py -q -m gpu -x --tb=short -s ;;
+    full) TAILN=40 run full 900 python -m pytest tests/test_full_shape_gpu.py -q -m gpu --tb=short -s ;;
     alltests) run alltests 1100 python -m pytest tests -q -m gpu -x --tb=short ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 900 python bench.py --steps 3 --warmup 1 ;;

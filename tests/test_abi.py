@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_abi_version_and_error_string(lib):
     L = lib.lib()
-    assert L.v2a_abi_version() == 2
+    assert L.v2a_abi_version() == 3
     g = lib.GemmArgs()
     g.nseg = 5
     assert L.v2a_gemm(ctypes.byref(g), None) == -1                 # V2A_ERR_ARG, before any HIP call
@@ -60,6 +60,45 @@ def test_struct_layout_matches_header(lib):
             names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*$", part.strip())[0])
     assert names == [f[0] for f in lib.GemmArgs._fields_]
     assert ctypes.sizeof(lib.GemmArgs) % 8 == 0
+    # the library reports the struct size it was compiled with: the ctypes mirror must agree byte for byte
+    assert lib.lib().v2a_gemm_args_size() == ctypes.sizeof(lib.GemmArgs)
+
+
+def _struct_fields(src, name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        for part in decl.strip().split(","):
+            part = part.strip()
+            if part:
+                names.append(re.findall(r"\*?\s*([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*$", part)[0])
+    return names
+
+
+def test_integration_md_binding_matches_header(lib):
+    """The ctypes stub a maintainer would copy out of INTEGRATION.md section 1 mirrors v2a_gemm_args field for field
+    (a short struct makes the kernel read garbage pointers), and the tuning struct mirrors v2a_tuning."""
+    src = open(os.path.join(ROOT, "include", "v2a_cfm.h")).read()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"class GemmArgs\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n\n", md, re.S).group(1)
+    md_fields = re.findall(r'\("([a-z_0-9A-Z]+)",', block)
+    assert md_fields == _struct_fields(src, "v2a_gemm_args")
+    # the snippet is executable as printed: build the class from it and compare sizes with the library
+    ns = {}
+    code = re.search(r"(class GemmArgs\(ctypes\.Structure\):.*?\]\n)\n", md, re.S).group(1)
+    exec("import ctypes\n" + code, ns)
+    assert ctypes.sizeof(ns["GemmArgs"]) == lib.lib().v2a_gemm_args_size()
+    assert [f[0] for f in lib.Tuning._fields_] == _struct_fields(src, "v2a_tuning")
+
+
+def test_set_tuning_validates_and_resets(lib):
+    L = lib.lib()
+    t = lib.Tuning(9, 0, 0, 0)
+    assert L.v2a_set_tuning(ctypes.byref(t)) == -1 and b"gemm_force_tile" in L.v2a_last_error()
+    lib.set_tuning(force_tile=3, eight_phase=1)
+    lib.set_tuning()
+    assert L.v2a_set_tuning(None) == 0
 
 
 def test_roll_head_struct_and_new_entry_points_validate_on_cpu(lib):

@@ -206,6 +206,67 @@ def test_gemm_big_tile_persistent_configs(L, M, N, K, epi):
         torch.testing.assert_close(out.cpu().double(), ref, atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("stagger", [1, 2])
+@pytest.mark.parametrize("M,N,ks,epi", [(1564, 3088, (1024,), "store_rope"), (1564, 8192, (1024,), "geglu"), (300, 512, (64,), "store"),
+                                        (1564, 1024, (1024, 1280, 512), "resid"), (782, 1280, (128, 64), "gate_resid"),
+                                        (2600, 768, (192,), "store_f32"), (257, 272, (320,), "resid")])
+def test_gemm_8phase_kernel(L, M, N, ks, epi, stagger):
+    """The 256x256 phase-interleaved kernel (gemm_8phase.hip) forced for every shape: partial edge tiles in M and N, K loops
+    of 1, 2, 3 and many tiles, K-concatenated segments with different row strides, every fused epilogue, both wave-row
+    schedules (staggered / lock-step).  Checked against fp64 products of the bf16-rounded operands."""
+    K = sum(ks)
+    g = _g(M + N + K)
+    segs = [torch.randn(M, k, generator=g).bfloat16() for k in ks]
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = 0.1 * torch.randn(N, generator=g)
+    acc = torch.cat(segs, 1).float().double() @ w.float().double().t() + bias.double()
+    sd = [(t.to(DEV), t.shape[1], t.shape[1]) for t in segs]
+    wd, bd = w.to(DEV), bias.to(DEV)
+    L.set_tuning(force_tile=6, eight_phase=stagger)
+    try:
+        if epi == "store":
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            L.gemm(sd, wd, out, M=M, N=N, compute=L.BF16, bias=bd)
+            torch.testing.assert_close(out.float().cpu().double(), acc, atol=2e-2, rtol=2e-2)
+        elif epi == "store_f32":
+            out = torch.empty(M, N, device=DEV)
+            L.gemm(sd, wd, out, M=M, N=N, compute=L.BF16, bias=bd)
+            torch.testing.assert_close(out.cpu().double(), acc, atol=1e-4, rtol=1e-4)
+        elif epi == "store_rope":
+            rpb = 782
+            tab = _rope_table(rpb).to(DEV)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            L.gemm(sd, wd, out, M=M, N=N, compute=L.BF16, bias=bd, rope_table=tab, rope_cols=2048, rope_pos_offset=0, rows_per_batch=rpb)
+            q = acc[:, :2048].float().reshape(M // rpb, rpb, 32, 64).permute(0, 2, 1, 3)
+            fr = O.rotary_freqs(rpb, 64, "interleaved")
+            ref = acc.clone().float()
+            ref[:, :2048] = O.apply_rope(q, fr, "interleaved").permute(0, 2, 1, 3).reshape(M, 2048)
+            torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=2e-2)
+        elif epi == "geglu":
+            h = acc.reshape(M, N // 32, 2, 16)
+            ref = (h[:, :, 0] * torch.nn.functional.gelu(h[:, :, 1])).reshape(M, N // 2)
+            out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
+            L.gemm(sd, wd, out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_GEGLU, bias=bd, ldo=N // 2)
+            torch.testing.assert_close(out.float().cpu().double(), ref, atol=2e-2, rtol=2e-2)
+        elif epi == "resid":
+            resid = torch.randn(M, N, generator=g)
+            out = torch.empty(M, N, device=DEV)
+            sh = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            L.gemm(sd, wd, out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, bias=bd, resid=resid.to(DEV), out_bf16=sh)
+            torch.testing.assert_close(out.cpu().double(), resid.double() + acc, atol=2e-4, rtol=1e-4)
+            assert torch.equal(sh.cpu(), out.cpu().bfloat16())
+        else:
+            resid = torch.randn(M, N, generator=g)
+            gate = torch.rand(2, N, generator=g)
+            step = torch.tensor([1], dtype=torch.int32, device=DEV)
+            out = resid.to(DEV)
+            L.gemm(sd, wd, out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_GATE_RESID, bias=bd, resid=out, gate=gate.to(DEV),
+                   step=step, gate_step_stride=N, rows_per_batch=391)
+            torch.testing.assert_close(out.cpu().double(), resid.double() + gate[1].double() * acc, atol=2e-4, rtol=1e-4)
+    finally:
+        L.set_tuning()
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_gemm_three_segments_resid(L, mode):
     """concat-free TextAudioCrossCondition: W [N][Ka+Kb+Kc] against three fp32 row-major streams."""

@@ -43,6 +43,12 @@ class GemmArgs(C.Structure):
     ]
 
 
+class Tuning(C.Structure):
+    """Mirror of `v2a_tuning` (include/v2a_cfm.h): explicit tile-selection overrides, nothing is read from the environment."""
+    _fields_ = [("gemm_force_tile", C.c_int32), ("gemm_k_rotation", C.c_int32), ("gemm_8phase", C.c_int32),
+                ("gemm_8phase_min_tiles", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
@@ -64,7 +70,7 @@ class RollHeadArgs(C.Structure):
 
 
 EXPORTS = [
-    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
+    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
     "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
@@ -91,6 +97,8 @@ def _declare(lib):
     lib.v2a_abi_version.restype = C.c_int
     lib.v2a_last_error.restype = C.c_char_p
     lib.v2a_gemm.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.v2a_gemm_args_size.restype = C.c_int
+    lib.v2a_set_tuning.argtypes = [C.POINTER(Tuning)]
     lib.v2a_attention.argtypes = [C.POINTER(AttnArgs), vp]
     lib.v2a_rmsnorm.argtypes = [vp, i64, vp, i64, i32, i64, i32, vp, vp, i64, i64, i32, vp]
     lib.v2a_dwconv_silu_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
@@ -111,7 +119,7 @@ def _declare(lib):
     lib.v2a_lstm_layer.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.v2a_lstm2.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     for name in EXPORTS:
-        if name not in ("v2a_abi_version", "v2a_last_error"):
+        if name not in ("v2a_abi_version", "v2a_last_error", "v2a_gemm_args_size"):
             getattr(lib, name).restype = C.c_int
 
 
@@ -124,7 +132,16 @@ def lib():
                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the sampler.")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
+        if _lib.v2a_gemm_args_size() != C.sizeof(GemmArgs):
+            raise V2AError("libv2a_cfm.so was built with sizeof(v2a_gemm_args) = %d, this binding mirrors %d bytes: rebuild "
+                           "(csrc/build.sh)" % (_lib.v2a_gemm_args_size(), C.sizeof(GemmArgs)))
     return _lib
+
+
+def set_tuning(force_tile: int = -1, k_rotation: bool = False, eight_phase: int = 0, eight_phase_min_tiles: int = 0):
+    """Tile-selection overrides of v2a_gemm (A/B measurements); `set_tuning()` restores the automatic choice."""
+    t = Tuning(force_tile, 1 if k_rotation else 0, eight_phase, eight_phase_min_tiles)
+    check(lib().v2a_set_tuning(C.byref(t)))
 
 
 def check(rc: int):

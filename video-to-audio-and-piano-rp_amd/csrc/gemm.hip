@@ -8,364 +8,10 @@
 //          floats -- the parity mode, 1/16 of the bf16 rate by design.
 // Block = 256 threads = 4 waves in a 2x2 grid; wave tile (BM/2)x(BN/2) in 16x16 MFMA tiles.
 // Register-staged global->LDS with a 2-deep LDS ring and one barrier per K tile.
-#include "v2a_common.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "gemm_common.h"
 
 namespace {
 
-struct GemmParams {
-  const void* a[3];
-  int64_t lda[3];
-  int32_t kend[3];  // cumulative K end of each segment
-  int32_t nseg;
-  const void* w;
-  int64_t ldw;
-  const float* bias;
-  int32_t M, N, K;
-  void* out;
-  int64_t ldo;
-  bf16_t* out2;      // optional bf16 shadow of an fp32 output (operand of a later GEMM)
-  int64_t ldo2;
-  const float* resid;
-  int64_t ldr;
-  const float* gate;
-  const int32_t* step;
-  int64_t gss, gbs;
-  int32_t rpb;
-  const float* rope;     // cos/sin table [pos][32][2] or null: rotate interleaved pairs of columns < rope_cols (STORE epilogue)
-  int32_t rope_cols, rope_pos_off;
-  int32_t vec_epi;  // all epilogue pointers / strides allow 16-byte row pieces
-  int32_t relu;     // clamp the result at zero (conv + BatchNorm + ReLU blocks of the Video2Roll encoder)
-  // implicit-GEMM convolution (DMA kernel only): A row m starts at a[0] + a_rowoff[m], K tile kt adds a_koff[kt] (elements);
-  // out / resid / out2 row m starts at base + o_rowoff[m] instead of m * ld
-  const int32_t* a_rowoff;
-  const int32_t* a_koff;
-  const int32_t* o_rowoff;
-  int32_t krot;     // start each M band's K walk at a different K tile (see the kernel)
-};
-
-template <typename T> struct TileCfg;
-template <> struct TileCfg<bf16_t> {
-  static constexpr int BK = 64;
-  static constexpr int LDS_ROW = 64;  // elements per LDS row (128 B)
-};
-template <> struct TileCfg<float> {
-  static constexpr int BK = 16;
-  static constexpr int LDS_ROW = 20;  // padded: 80 B rows keep float4 writes aligned, 2-way max on reads
-};
-
-// ---- global -> register staging ----------------------------------------------------------
-// bf16 tile: ROWS x 64 bf16; thread t covers 16-B chunk (t & 7) of rows (t >> 3) + 32*i.
-template <int ROWS, bool SRC_F32> struct StageBf16 {
-  static constexpr int N = ROWS / 32;
-  bf16x8 r[N];
-  __device__ __forceinline__ void load(const void* base, int64_t ld, int row0, int rows_total, int k0, int tid) {
-    const int chunk = tid & 7;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      int row = row0 + (tid >> 3) + 32 * i;
-      row = row < rows_total ? row : rows_total - 1;
-      if constexpr (SRC_F32) {
-        const float* p = reinterpret_cast<const float*>(base) + (int64_t)row * ld + k0 + chunk * 8;
-        f32x4 lo = *reinterpret_cast<const f32x4*>(p);
-        f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = (bf16_t)lo[j];
-          v[4 + j] = (bf16_t)hi[j];
-        }
-        r[i] = v;
-      } else {
-        const bf16_t* p = reinterpret_cast<const bf16_t*>(base) + (int64_t)row * ld + k0 + chunk * 8;
-        r[i] = *reinterpret_cast<const bf16x8*>(p);
-      }
-    }
-  }
-  __device__ __forceinline__ void store(bf16_t* lds, int tid) const {
-    const int chunk = tid & 7;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      int row = (tid >> 3) + 32 * i;
-      *reinterpret_cast<bf16x8*>(lds + row * 64 + ((chunk ^ (row & 7)) << 3)) = r[i];
-    }
-  }
-};
-
-// fp32 tile: ROWS x 16 floats; thread t covers float4 (t & 3) of rows (t >> 2) + 64*i.
-template <int ROWS> struct StageF32 {
-  static constexpr int N = ROWS / 64;
-  f32x4 r[N];
-  __device__ __forceinline__ void load(const void* base, int64_t ld, int row0, int rows_total, int k0, int tid) {
-    const int c4 = tid & 3;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      int row = row0 + (tid >> 2) + 64 * i;
-      row = row < rows_total ? row : rows_total - 1;
-      const float* p = reinterpret_cast<const float*>(base) + (int64_t)row * ld + k0 + c4 * 4;
-      r[i] = *reinterpret_cast<const f32x4*>(p);
-    }
-  }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
-    const int c4 = tid & 3;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      int row = (tid >> 2) + 64 * i;
-      *reinterpret_cast<f32x4*>(lds + row * 20 + c4 * 4) = r[i];
-    }
-  }
-};
-
-template <typename T, bool A_F32, int ROWS> struct StageSel;
-template <bool A_F32, int ROWS> struct StageSel<bf16_t, A_F32, ROWS> { using type = StageBf16<ROWS, A_F32>; };
-template <bool A_F32, int ROWS> struct StageSel<float, A_F32, ROWS> { using type = StageF32<ROWS>; };
-
-// ---- shared epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + j ------------------
-template <int EPI, typename OutT, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                              int lr, int lq) {
-  OutT* out = reinterpret_cast<OutT*>(p.out);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int m = m0 + wm * WM + i * 16 + lq * 4 + jj;
-      if (m >= p.M) continue;
-      const float* gvec = nullptr;
-      if constexpr (EPI == V2A_EPI_GATE_RESID) gvec = step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb);
-      if constexpr (EPI == V2A_EPI_GEGLU) {
-#pragma unroll
-        for (int j = 0; j < TN; j += 2) {
-          const int n = n0 + wn * WN + j * 16 + lr;  // packed row index of the value
-          if (n >= p.N) continue;
-          float v = acc[i][j][jj], g = acc[i][j + 1][jj];
-          if (p.bias) { v += p.bias[n]; g += p.bias[n + 16]; }
-          const int oc = ((n0 + wn * WN) >> 1) + (j >> 1) * 16 + lr;
-          const float ge = sizeof(OutT) == 2 ? gelu_fast_f(g) : gelu_erf_f(g);
-          out[(int64_t)m * p.ldo + oc] = from_f32<OutT>(v * ge);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * WN + j * 16 + lr;
-          if (n >= p.N) continue;
-          float v = acc[i][j][jj];
-          if (p.bias) v += p.bias[n];
-          if constexpr (EPI == V2A_EPI_SIGMOID) v = sigmoid_f(v);
-          if constexpr (EPI == V2A_EPI_RESID) v += p.resid[(int64_t)m * p.ldr + n];
-          if constexpr (EPI == V2A_EPI_GATE_RESID) v = p.resid[(int64_t)m * p.ldr + n] + gvec[n] * v;
-          if (p.relu) v = fmaxf(v, 0.f);
-          out[(int64_t)m * p.ldo + n] = from_f32<OutT>(v);
-          if constexpr (sizeof(OutT) == 4) {
-            if (p.out2) p.out2[(int64_t)m * p.ldo2 + n] = (bf16_t)v;
-          }
-        }
-      }
-    }
-  }
-}
-
-
-// ---- LDS-staged epilogue (DMA kernels) -----------------------------------------------------
-// The MFMA C layout gives a lane 4 ROWS of one column, so direct stores are 2-4 byte pieces.
-// Instead every wave parks its WM x WN fp32 tile in a private LDS region (the K-loop stages are
-// dead by then), and reads it back row-major 4 columns per lane: bias / GELU / gate / residual run
-// on float4s and every global access is a 16-byte (fp32) or 8-byte (bf16) piece of a contiguous row.
-// Residual / gate pieces of the vector epilogue, fetched at kernel start so their L2/HBM latency hides under the K loop
-// instead of being paid once per 16-row slab at the tail of every workgroup (same lane -> (row, 4 columns) map as below).
-template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
-  static constexpr int LPR = WN / 4, RPI = 64 / LPR, RPS = 16 / RPI;   // lanes per row, rows per pass, rows per slab and lane
-  static constexpr bool RES = ON && (EPI == V2A_EPI_RESID || EPI == V2A_EPI_GATE_RESID);
-  static constexpr bool GATE = ON && EPI == V2A_EPI_GATE_RESID;
-  f32x4 rs[RES ? TM : 1][RES ? RPS : 1];
-  f32x4 gt[GATE ? TM : 1][GATE ? RPS : 1];
-  static constexpr bool SCAT = RES && !GATE;   // offset tables come with STORE / RESID only (checked on the host)
-  int32_t ro[SCAT ? TM : 1][SCAT ? RPS : 1];  // out / resid row offsets when rows are scattered (o_rowoff)
-  static constexpr bool ROPE = ON && EPI == V2A_EPI_STORE;
-  f32x4 cs[ROPE ? TM : 1][ROPE ? RPS : 1];     // (cos, sin) of the two column pairs a lane rotates
-  __device__ __forceinline__ void load(const GemmParams& p, int m_base, int n_base, int lane) {
-    if constexpr (ROPE) {
-      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-      const int n = n_base + c4;
-      if (p.rope && n < p.rope_cols) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int q = 0; q < RPS; ++q) {
-            int m = m_base + i * 16 + r0 + q * RPI;
-            m = m < p.M ? m : p.M - 1;
-            const int pos = p.rope_pos_off + m % p.rpb;
-            cs[i][q] = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)pos * 32 + ((n & 63) >> 1)) * 2);
-          }
-      }
-    }
-    if constexpr (RES) {
-      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-      const int n = n_base + c4;
-      // kernel arguments copied once: the loops below stay free of scalar re-loads and branches
-      const int M = p.M;
-      const bool full = n + 3 < p.N;
-      const float* resid = p.resid + n;
-      const int64_t ldr = p.ldr;
-      const int32_t* orow = SCAT ? p.o_rowoff : nullptr;
-      // scattered rows (implicit-GEMM convolution): all row offsets are requested before the first residual row depends on one
-      if constexpr (SCAT) {
-        if (orow) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < RPS; ++q) {
-              int m = m_base + i * 16 + r0 + q * RPI;
-              m = m < M ? m : M - 1;
-              ro[i][q] = orow[m];
-            }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < RPS; ++q) {
-          const int m = m_base + i * 16 + r0 + q * RPI;
-          if (m < M && full) {
-            int64_t off = (int64_t)m * ldr;
-            if constexpr (SCAT) { if (orow) off = ro[i][q]; }
-            rs[i][q] = *reinterpret_cast<const f32x4*>(resid + off);
-            if constexpr (GATE) gt[i][q] = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
-          }
-        }
-    }
-  }
-};
-
-template <int EPI, typename OutT, int TM, int TN, int WM, int WN, bool PF>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[TM][TN], float* tile /* wave-private, 16 x (WN+4) floats */,
-                                                  int m_base, int n_base, int lane, const EpiPrefetch<EPI, TM, WN, PF>& pf) {
-  constexpr int LD = WN + 4;                   // 16-B aligned rows, <= 2-way write conflicts
-  const int lr = lane & 15, lq = lane >> 4;
-  OutT* out = reinterpret_cast<OutT*>(p.out);
-  // kernel arguments copied once (the slab loops below otherwise re-load them from the argument segment per row)
-  const int M = p.M;
-  const bool relu = p.relu != 0;
-  const int32_t* orow = p.o_rowoff;           // scattered rows (implicit-GEMM convolution into a bordered map) or null
-  const int64_t ldo = p.ldo, ldr = p.ldr, ldo2 = p.ldo2;
-  bf16_t* out2 = p.out2;
-  const float* resid = p.resid;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    // one 16-row slab of the wave tile at a time: the staging area of a workgroup is a few KB of one ring stage
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) tile[(lq * 4 + jj) * LD + j * 16 + lr] = acc[i][j][jj];
-    // same wave wrote and reads: LDS operations of one wave complete in order, no barrier needed
-    if constexpr (EPI == V2A_EPI_GEGLU) {
-      constexpr int OC = WN / 2;                 // output columns of this wave
-      constexpr int LPR = OC / 4;                // lanes per row
-      constexpr int RPI = 64 / LPR;              // rows per pass
-      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-      const int lc = (c4 >> 4) * 32 + (c4 & 15); // LDS column of the value; gate is 16 further
-      const int n = n_base + lc;                 // packed W row of the value
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && n < p.N) {
-        bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-        bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
-      }
-#pragma unroll
-      for (int r = r0; r < 16; r += RPI) {
-        const int m = m_base + i * 16 + r;
-        if (m >= p.M || n >= p.N) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
-        OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
-        if constexpr (sizeof(OutT) == 2) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[e] + bv[e]) * gelu_fast_f(g[e] + bg[e]));
-          *reinterpret_cast<bf16x4*>(dst) = o;
-        } else {
-          f32x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (v[e] + bv[e]) * gelu_erf_f(g[e] + bg[e]);
-          *reinterpret_cast<f32x4*>(dst) = o;
-        }
-      }
-    } else {
-      constexpr int LPR = WN / 4;
-      constexpr int RPI = 64 / LPR;
-      const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-      const int n = n_base + c4;
-      const bool full = n + 3 < p.N;             // N is a multiple of 4 for every vector-eligible call (checked on the host)
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && full) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-      for (int q = 0; q < 16 / RPI; ++q) {
-        const int r = r0 + q * RPI;
-        const int m = m_base + i * 16 + r;
-        if (m >= M || !full) continue;
-        int64_t o_out = (int64_t)m * ldo, o_res = (int64_t)m * ldr, o_out2 = (int64_t)m * ldo2;
-        if constexpr (EPI == V2A_EPI_STORE || EPI == V2A_EPI_RESID) {     // offset tables come with STORE / RESID only
-          if (orow) {
-            int64_t ro;
-            if constexpr (PF && EPI == V2A_EPI_RESID) ro = pf.ro[i][q];
-            else ro = orow[m];
-            o_out = o_res = o_out2 = ro;
-          }
-        }
-        f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bv[e];
-        if constexpr (EPI == V2A_EPI_SIGMOID) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
-        }
-        if constexpr (EPI == V2A_EPI_STORE) {
-          if (p.rope && n < p.rope_cols) {
-            // interleaved RoPE (A6): columns (n, n+1) and (n+2, n+3) are pairs (n & 63) / 2 and +1 of this head
-            f32x4 cs;
-            if constexpr (PF) cs = pf.cs[i][q];
-            else cs = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)(p.rope_pos_off + m % p.rpb) * 32 + ((n & 63) >> 1)) * 2);
-            const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
-            v[0] = a0 * cs[0] - b0 * cs[1];
-            v[1] = b0 * cs[0] + a0 * cs[1];
-            v[2] = a1 * cs[2] - b1 * cs[3];
-            v[3] = b1 * cs[2] + a1 * cs[3];
-          }
-        }
-        if constexpr (EPI == V2A_EPI_RESID || EPI == V2A_EPI_GATE_RESID) {
-          f32x4 rs, gt = {1.f, 1.f, 1.f, 1.f};
-          if constexpr (PF) {
-            rs = pf.rs[i][q];
-            if constexpr (EPI == V2A_EPI_GATE_RESID) gt = pf.gt[i][q];
-          } else {
-            rs = *reinterpret_cast<const f32x4*>(resid + o_res + n);
-            if constexpr (EPI == V2A_EPI_GATE_RESID) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
-        }
-        if (relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if constexpr (sizeof(OutT) == 2) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x4*>(out + o_out + n) = o;
-        } else {
-          *reinterpret_cast<f32x4*>(out + o_out + n) = v;
-          if (out2) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x4*>(out2 + o_out2 + n) = o;
-          }
-        }
-      }
-    }
-  }
-}
 
 // ---- the kernel ---------------------------------------------------------------------------
 template <typename T, bool A_F32, int EPI, typename OutT, int BM, int BN>
@@ -483,11 +129,9 @@ int launch(const GemmParams& p, hipStream_t s) {
   constexpr size_t smem = 2 * (size_t)(BM + BN) * LR * sizeof(T);
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   auto kern = gemm_kernel<T, A_F32, EPI, OutT, BM, BN>;
-  static bool attr_set = false;  // > 64 KB dynamic LDS is opt-in
-  if (!attr_set && smem > 48 * 1024) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  // > 64 KB dynamic LDS is opt-in; a function-local static is initialised exactly once, thread-safely (C++11)
+  static const hipError_t attr = smem > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) : hipSuccess;
+  (void)attr;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, p);
   return v2a_check_launch("v2a_gemm");
 }
@@ -714,11 +358,8 @@ int launch_dma(const GemmParams& p, hipStream_t s) {
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
   auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  (void)attr;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WGM * WGN), smem, s, p);
   return v2a_check_launch("v2a_gemm(dma)");
 }
@@ -743,6 +384,22 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = {-1, 0, 0, 64};
+
+extern "C" int v2a_gemm_args_size(void) { return (int)sizeof(v2a_gemm_args); }
+
+extern "C" int v2a_set_tuning(const v2a_tuning* t) {
+  if (!t) {
+    v2a_detail::g_gemm_tuning = {-1, 0, 0, 64};
+    return V2A_OK;
+  }
+  V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 6, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
+  V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
+  v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,
+                               t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : 64};
+  return V2A_OK;
+}
 
 extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   V2A_REQUIRE(a != nullptr, "v2a_gemm: null args");
@@ -799,9 +456,9 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   }
   p.relu = a->relu;
   // off by default: +0.7 % throughput, but the fp32 summation order of a row then depends on how many rows the call has, so a
-  // clip's result would change (in the last bits) with the batch it is sampled in; V2A_GEMM_KROT=1 enables it
-  static const int krot = getenv("V2A_GEMM_KROT") ? atoi(getenv("V2A_GEMM_KROT")) : 0;
-  p.krot = krot;
+  // clip's result would change (in the last bits) with the batch it is sampled in; v2a_set_tuning enables it
+  const v2a_detail::GemmTuning tune = v2a_detail::g_gemm_tuning;
+  p.krot = tune.krot;
   p.a_rowoff = a->a_row_offset;
   p.a_koff = a->a_ktile_offset;
   p.o_rowoff = a->out_row_offset;
@@ -830,16 +487,16 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   if (a->epilogue == V2A_EPI_SIGMOID) return dispatch_epi<bf16_t, false, 128, 128>(a, p, s);
   // bf16 x bf16: LDS-DMA kernel; tile shape by how many workgroups the problem yields (256 CUs)
   auto ntiles = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
-  static const int force = getenv("V2A_GEMM_TILE") ? atoi(getenv("V2A_GEMM_TILE")) : -1;   // tuning aid
-  static const int small = getenv("V2A_GEMM_SMALL") ? atoi(getenv("V2A_GEMM_SMALL")) : -1;
-  static const int big = getenv("V2A_GEMM_BIG") ? atoi(getenv("V2A_GEMM_BIG")) : 1;          // 0: never use the 256x256 tile
+  // wide outputs: 256x256 tile with the phase-interleaved K loop (gemm_8phase.hip) once the problem yields enough tiles
+  const bool dense = !a->a_row_offset && !a->out_row_offset && p.vec_epi;
+  if (tune.force_tile == 6 || (tune.force_tile < 0 && tune.use_8phase && dense && a->N >= 2048 && ntiles(256, 256) >= tune.min_tiles_8phase))
+    return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
   int cfg;
-  if (force >= 0) cfg = force;
+  if (tune.force_tile >= 0) cfg = tune.force_tile;
   else if (a->N <= 64) cfg = ntiles(128, 64) >= 512 ? 2 : 3;          // conv layers with few output channels
   else if (a->N <= 128) cfg = ntiles(128, 128) >= 512 ? 1 : (ntiles(128, 64) >= 512 ? 2 : 3);
-  else if (big && ntiles(256, 256) >= 512 && a->N >= 2048) cfg = 5;   // batched clips, wide outputs: halve the fill bytes per flop
+  else if (ntiles(256, 256) >= 512 && a->N >= 2048) cfg = 5;          // batched clips, wide outputs: halve the fill bytes per flop
   else if ((a->N >= 2048 && ntiles(128, 256) >= 96) || ntiles(128, 256) >= 200) cfg = 0;   // wide outputs, or large M
-  else if (small >= 0) cfg = small;                                     // tuning aid: V2A_GEMM_SMALL
   else if (ntiles(128, 128) >= 256) cfg = 1;                            // batched clips, narrow outputs
   else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;
   else cfg = 3;

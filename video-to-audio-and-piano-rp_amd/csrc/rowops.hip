@@ -6,7 +6,7 @@
 
 thread_local char v2a_err_buf[512] = {0};
 
-extern "C" int v2a_abi_version(void) { return 2; }
+extern "C" int v2a_abi_version(void) { return 3; }
 extern "C" const char* v2a_last_error(void) { return v2a_err_buf; }
 
 namespace {

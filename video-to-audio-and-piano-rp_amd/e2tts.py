@@ -342,9 +342,11 @@ class E2TTS:
                return_raw_output=None, save_to_filename=None, prompt=None, video_drop_prompt=None,
                audio_drop_prompt=None, video_paths=None, frames=None, midis=None,
                # build-side extensions
-               y0=None, text_embed=None, context=None, context_mask=None, frames_embed=None):
+               y0=None, text_embed=None, context=None, context_mask=None, frames_embed=None, trajectory_out=None):
         """x3:2127-2305.  `cond` (b, n, C) only fixes shape/device here (lens == duration on every
-        shipped call, so it is never used as audio conditioning: predict.py:261-263)."""
+        shipped call, so it is never used as audio conditioning: predict.py:261-263).
+        `trajectory_out`: optional list that receives a device copy of y at every grid point (the `trajectory` of
+        x3:2255, of which the reference keeps only [-1]); test aid, adds a copy per step."""
         self.eval()
         if cond.ndim == 2:
             raise NotImplementedError("raw-wave `cond` needs mel_spec_module, which the shipped config does not set")
@@ -410,7 +412,7 @@ class E2TTS:
             p["y"] = torch.empty(batch, n, cfgm.num_channels, dtype=torch.float32, device=self._device)
         eng.prepare(text_embed, frames_embed, context, context_mask, t[:-1], lens=duration,
                     drop_ctx=drop_ctx, dt=t[1:] - t[:-1])
-        self._run_steps(eng, y0, S, float(cfg_strength), bool(remove_parallel_component))
+        self._run_steps(eng, y0, S, float(cfg_strength), bool(remove_parallel_component), trajectory_out)
         out = p["y"].to(out_device).clone()
         if return_raw_output:
             return out
@@ -430,16 +432,20 @@ class E2TTS:
                 torchaudio.save(str(path.parents[0] / name), one.detach().cpu()[None], sample_rate=self.sampling_rate)
         return audio
 
-    def _run_steps(self, eng: DiTEngine, y0, S, cfg_strength, apg):
+    def _run_steps(self, eng: DiTEngine, y0, S, cfg_strength, apg, traj=None):
         """steps-1 Euler evaluations (A12 of SURVEY 8c).  cfg_strength < 1e-5 (x3:2101) still
         runs the batched pass; the null half then has weight 0."""
         p = eng.plan
         y = p["y"]
         y.copy_(y0.to(self._device, torch.float32))
         p["step"].zero_()
+        if traj is not None:
+            traj.append(y.clone())
         if not self._use_graph:
             for _ in range(S):
                 eng.euler_step(y, cfg_strength, apg)
+                if traj is not None:
+                    traj.append(y.clone())
             return
         key = (p["key"], cfg_strength, apg, p["ragged"])
         g = self._graphs.get(key)
@@ -458,6 +464,8 @@ class E2TTS:
             self._graphs = {key: g}          # one plan is live at a time; drop graphs of older plans
         for _ in range(S):
             g.replay()
+            if traj is not None:
+                traj.append(y.clone())
 
 
 def _mask_to_lens(mask: torch.Tensor) -> torch.Tensor:
