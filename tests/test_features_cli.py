@@ -9,28 +9,16 @@ import v2a_amd
 from v2a_amd import cli
 
 
-def _reference_loop(image_embeddings, duration, l, sampling_rate=24000, frame_size=320, start_sample=0, max_sample=None):
-    """The resampling loop as written at e2_tts_crossatt3.py:1801-1813 (restated for the test)."""
-    if max_sample is None:
-        max_sample = int(duration * sampling_rate)
-    interpolated = []
-    for i in range(start_sample, max_sample, frame_size):
-        j = min(round((i + frame_size // 2) / sampling_rate / (duration / (image_embeddings.shape[0] - 1))), image_embeddings.shape[0] - 1)
-        interpolated.append(image_embeddings[j:j + 1])
-        if len(interpolated) >= l:
-            break
-    return torch.cat(interpolated, dim=0)
-
-
 @pytest.mark.parametrize("nf,duration,l", [(240, 10.0, 750), (251, 10.04, 750), (30, 1.3, 750), (300, 10.0, 400), (2, 0.5, 750)])
-def test_resampler_matches_reference_loop(nf, duration, l):
+def test_resampler_properties(nf, duration, l):
+    """Shape / monotonicity properties; the index values themselves are checked against the reference's own loop in
+    tests/test_intree_golden.py::test_resample_indices_match_reference_loop (fixture produced by x3:1800-1808)."""
     emb = torch.randn(nf, 16, generator=torch.Generator().manual_seed(nf))
-    ref = _reference_loop(emb, duration, l)
     got = v2a_amd.resample_clip_features(emb, duration, l)
     assert got.shape == (l, 16)
-    assert torch.equal(got[: ref.shape[0]], ref) and float(got[ref.shape[0]:].abs().max() if ref.shape[0] < l else 0) == 0
     idx = v2a_amd.resample_indices(nf, duration, l)
     assert idx == sorted(idx) and idx[0] == 0 and max(idx) <= nf - 1
+    assert torch.equal(got[: len(idx)], emb[torch.tensor(idx)])
     if nf == 240 and l == 750:         # 24 fps -> 75 Hz: runs of ~3 latent frames per video frame
         assert len(idx) == 750 and 230 < len(set(idx)) <= 240
 

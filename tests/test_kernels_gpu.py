@@ -495,3 +495,70 @@ def test_cfg_euler(L, apg):
     L.step_advance(step)
     torch.testing.assert_close(yd.cpu(), ref, atol=1e-5, rtol=1e-5)
     assert int(step.item()) == 2
+
+
+# --------------------------------------------------- HIP rows against vectors produced by the reference's own code
+@pytest.fixture(scope="module")
+def intree():
+    import os
+    from conftest import GOLDEN
+    d = dict(np.load(os.path.join(GOLDEN, "intree_blocks.npz"), allow_pickle=False))
+    d.pop("meta")
+    return {k: torch.from_numpy(v) for k, v in d.items()}
+
+
+def test_cfg_euler_apg_vs_reference_project(L, intree):
+    """a2: v2a_apg_reduce + v2a_cfg_euler with remove_parallel_component against `project` (x3:162-173) run from the
+    reference file itself: y + dt * (pc + s * (orthogonal + keep * parallel)),  (parallel, orthogonal) = project(pc - pn, pc)."""
+    r = intree
+    pc = r["project_y"]                                     # project(update, pred): y is the conditional prediction
+    upd, par, orth = r["project_x"], r["project_parallel"], r["project_orthogonal"]
+    pn = pc - upd
+    B, T, C = pc.shape
+    R, s, keep, dt = 4, 2.0, 0.25, 0.125
+    pred = torch.zeros(2 * B, R + T, C)
+    pred[:B, R:], pred[B:, R:] = pc, pn
+    y = torch.randn(B, T, C, generator=_g(3))
+    want = y + dt * (pc + s * (orth + keep * par))
+    yd, pd = y.to(DEV), pred.to(DEV)
+    apg = torch.zeros(2 * B, dtype=torch.float64, device=DEV)
+    kw = dict(B=B, T=T, C_=C, pred_batch_stride=(R + T) * C, row_off=R)
+    L.apg_reduce(pd, apg, **kw)
+    L.cfg_euler(yd, pd, cfg_strength=s, dt=torch.tensor([dt], device=DEV), step=None, apg=apg, keep=keep, **kw)
+    torch.testing.assert_close(yd.cpu(), want, atol=2e-6, rtol=1e-6)
+
+
+def test_adaln_zero_vs_reference_module(L, intree):
+    """a12: gate table by the SIGMOID epilogue, applied by GATE_RESID (resid = 0, identity weight: out = gate * x) against
+    `AdaLNZero.forward` (x3:546-551) run from the reference file itself."""
+    r = intree
+    x, cond, w, b = r["adaln_x"], r["adaln_cond"], r["adaln_w"], r["adaln_b"]
+    Bt, N, d = x.shape
+    tab = torch.empty(Bt, d, device=DEV)
+    L.gemm([(cond.to(DEV), d, d)], w.to(DEV), tab, M=Bt, N=d, compute=L.F32, epilogue=L.EPI_SIGMOID, bias=b.to(DEV))
+    out = torch.zeros(Bt * N, d, device=DEV)
+    L.gemm([(x.reshape(-1, d).to(DEV), d, d)], torch.eye(d, device=DEV), out, M=Bt * N, N=d, compute=L.F32, epilogue=L.EPI_GATE_RESID,
+           resid=out, gate=tab, gate_batch_stride=d, rows_per_batch=N)
+    torch.testing.assert_close(out.cpu().reshape(Bt, N, d), r["adaln_out"], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("flag", [1, 0])
+def test_cross_condition_vs_reference_module(L, intree, flag):
+    """a13: the three concat-free multi-segment GEMMs against `TextAudioCrossCondition.forward` (x3:686-702) run from
+    the reference file itself (fp32 mode), all reading the pre-update streams."""
+    r = intree
+    a, t, f = r["cc_audio"], r["cc_text"], r["cc_frames"]
+    Bt, N, da = a.shape
+    dt, df = t.shape[-1], f.shape[-1]
+    M = Bt * N
+    ad, td, fd = (v.reshape(M, -1).to(DEV) for v in (a, t, f))
+    oa = torch.empty(M, da, device=DEV)
+    L.gemm([(ad, da, da), (td, dt, dt), (fd, df, df)], r[f"cc_{flag}_text_frames_to_audio_weight"].to(DEV), oa, M=M, N=da, compute=L.F32,
+           epilogue=L.EPI_RESID, resid=ad)
+    torch.testing.assert_close(oa.cpu().reshape(Bt, N, da), r[f"cc_{flag}_out_audio"], atol=2e-5, rtol=1e-5)
+    if flag:
+        ot, of = torch.empty(M, dt, device=DEV), torch.empty(M, df, device=DEV)
+        L.gemm([(ad, da, da), (td, dt, dt)], r["cc_1_audio_to_text_weight"].to(DEV), ot, M=M, N=dt, compute=L.F32, epilogue=L.EPI_RESID, resid=td)
+        L.gemm([(ad, da, da), (fd, df, df)], r["cc_1_audio_to_frames_weight"].to(DEV), of, M=M, N=df, compute=L.F32, epilogue=L.EPI_RESID, resid=fd)
+        torch.testing.assert_close(ot.cpu().reshape(Bt, N, dt), r["cc_1_out_text"], atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(of.cpu().reshape(Bt, N, df), r["cc_1_out_frames"], atol=2e-5, rtol=1e-5)

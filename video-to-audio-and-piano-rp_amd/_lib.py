@@ -170,17 +170,30 @@ _prof = None
 
 
 class KernelProfiler:
-    """Brackets every C-ABI launch with a pair of events recorded on the stream the kernel is
-    launched on (torch's current stream) and aggregates by kernel instantiation."""
+    """Per-launch timing of the C-ABI calls with HIP events on the stream the kernel is launched on (torch's current
+    stream), aggregated by kernel instantiation.
 
-    def __init__(self, shapes: bool = False, inner: int = 1):
+    external=False : eager -- every launch sits between its own pair of events (`inner` back-to-back launches per pair for
+                     GEMMs amortise the ~5 us dispatch gap an eager pair includes, at the price of warm caches).
+    external=True  : for use under hipGraph capture -- ONE external event is recorded in front of every launch (an event
+                     record node of the graph) and one after the last; after each replay `collect()` adds the interval to
+                     the next mark to the launch's total.  Intervals are kernel time + the launch boundary behind it, with
+                     every kernel launched exactly once per evaluation in its real cache state."""
+
+    def __init__(self, shapes: bool = False, inner: int = 1, external: bool = False):
         self.recs = []
         self.shapes = shapes      # key GEMM launches by MxNxK as well
-        self.inner = inner        # GEMMs: this many back-to-back launches per event pair, so the dispatch gap an
-                                  # eager event pair includes (~5 us) is amortised and the per-launch time matches
-                                  # the kernel duration a profiler reports (timing only: in-place epilogues repeat)
+        self.inner = inner
+        self.external = external
+        self.marks, self.end, self.tot = [], None, {}
 
     def launch(self, key, flops, nbytes, call):
+        if self.external:
+            e = torch.cuda.Event(enable_timing=True, external=True)
+            e.record()
+            self.marks.append((key, flops, nbytes, e))
+            call()
+            return
         n = self.inner if key.startswith("gemm") else 1
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -189,8 +202,25 @@ class KernelProfiler:
         e.record()
         self.recs.append((key, flops, nbytes, s, e, n))
 
+    def close(self):
+        """external mode: the mark behind the last launch (call inside the capture)."""
+        self.end = torch.cuda.Event(enable_timing=True, external=True)
+        self.end.record()
+
+    def collect(self):
+        """external mode: after a replay has completed, add this replay's intervals."""
+        for i, (key, flops, nbytes, e) in enumerate(self.marks):
+            nxt = self.marks[i + 1][3] if i + 1 < len(self.marks) else self.end
+            a = self.tot.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += e.elapsed_time(nxt)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+
     def summary(self):
         torch.cuda.synchronize()
+        if self.external:
+            return self.tot
         agg = {}
         for key, flops, nbytes, s, e, n in self.recs:
             a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))

@@ -410,9 +410,14 @@ class E2TTS:
         p = eng.plan
         if "y" not in p:
             p["y"] = torch.empty(batch, n, cfgm.num_channels, dtype=torch.float32, device=self._device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         eng.prepare(text_embed, frames_embed, context, context_mask, t[:-1], lens=duration,
                     drop_ctx=drop_ctx, dt=t[1:] - t[:-1])
+        ev[1].record()
         self._run_steps(eng, y0, S, float(cfg_strength), bool(remove_parallel_component), trajectory_out)
+        ev[2].record()
+        self._phase_events = ev          # device-side phase marks of this call (no host sync here): see phase_ms()
         out = p["y"].to(out_device).clone()
         if return_raw_output:
             return out
@@ -431,6 +436,14 @@ class E2TTS:
                 name = path.name if len(audio) == 1 else f"{ind + 1}.{path.name}"
                 torchaudio.save(str(path.parents[0] / name), one.detach().cpu()[None], sample_rate=self.sampling_rate)
         return audio
+
+    def phase_ms(self):
+        """(prepare_ms, euler_loop_ms) of the last sample() call, from events on the launch stream; synchronises."""
+        ev = getattr(self, "_phase_events", None)
+        if ev is None:
+            return None
+        ev[2].synchronize()
+        return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
 
     def _run_steps(self, eng: DiTEngine, y0, S, cfg_strength, apg, traj=None):
         """steps-1 Euler evaluations (A12 of SURVEY 8c).  cfg_strength < 1e-5 (x3:2101) still
