@@ -13,10 +13,16 @@ shapes; they are resident in HBM before the timed region, which covers everythin
 of latents.  Ranks are clip-sharded (weak scaling, no per-step communication).
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries
-  roofline     : the dominant kernel (bf16 MFMA GEMM instantiation with the most time), measured
-                 with HIP events on the launch stream over an eager replay of one Euler evaluation;
+  roofline     : the dominant kernel (bf16 MFMA GEMM instantiation with the most time per evaluation), measured live with
+                 HIP events recorded BETWEEN the nodes of a single-stream hipGraph of one Euler evaluation (every kernel
+                 launched once, in its real cache state; interval = kernel + the launch boundary behind it), plus an
+                 `hbm` block for the memory-bound kernels at 1 and 8 clips per GPU;
+  parity_mode  : throughput AND max |delta mel| over the whole 32-point grid against the committed oracle vector
+                 (tests/golden/sample_full.npz) for the fp32 parity mode and the bf16 headline mode;
+  v2p, cascade : BASELINE configs[3] / [4] as supplementary measurements;
   cpu_baseline : the CPU restatement of the reference (oracle/, "port") timed on this box's host
-                 cores on a bounded sample of the same workload.
+                 cores on a bounded sample of the same workload (steps=4: 3 CFG evaluations).
+With N > 1 the default is 8 clips per GPU (BASELINE configs[2]: 64 clips on 8 GPUs).
 """
 from __future__ import annotations
 
@@ -53,6 +59,7 @@ _T0 = time.perf_counter()
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PMC_FILES = ("r01_pmc1_summary.csv", "r01_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
 
 
 def main():
@@ -60,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5, help="timed sample() calls")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips-per-gpu", type=int, default=1, help="configs[1] is one 10 s clip; configs[2] uses 8")
+    ap.add_argument("--clips-per-gpu", type=int, default=0, help="0 = 1 clip at --gpus 1 (configs[1]), 8 clips per GPU at --gpus N > 1 (configs[2])")
     ap.add_argument("--cfm-steps", type=int, default=32)
     ap.add_argument("--cfg-strength", type=float, default=2.0)
     ap.add_argument("--frames", type=int, default=750)
@@ -75,7 +82,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="print a per-GEMM-shape timing table to stderr")
     ap.add_argument("--no-batched", action="store_true", help="skip the supplementary 8-clips-per-GPU measurement (N=1 only)")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="grid points of the bounded CPU sample")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="grid points of the bounded CPU sample (SURVEY 8d: steps=4)")
+    ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered, 2 lock-step)")
+    ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the supplementary configs[3] (V2P) and configs[4] (cascade) legs")
+    ap.add_argument("--eager-roofline", action="store_true", help="time kernels with eager event pairs instead of events between graph nodes")
     ap.add_argument("--no-video2roll", action="store_true", help="skip the supplementary Video2Roll frame-encoder measurement (SURVEY 8f N2)")
     ap.add_argument("--no-vocoder", action="store_true", help="skip the supplementary Encodec-decoder measurement (SURVEY 8f N1)")
     ap.add_argument("--video2roll-frames", type=int, default=251, help="video frames per clip: floor(750 / 3) + 1 (x3:1913)")
@@ -101,7 +113,11 @@ def main():
     from v2a_amd import _lib as L
     from v2a_amd.synth import random_state_dict, synthetic_conditioning
 
+    if args.gemm_8phase >= 0:
+        L.set_tuning(eight_phase=args.gemm_8phase, eight_phase_min_tiles=args.gemm_8phase_min_tiles)
     cfg = v2a_amd.DiTConfig()
+    if args.clips_per_gpu <= 0:
+        args.clips_per_gpu = 1 if world == 1 else 8
     B, T, NC = args.clips_per_gpu, args.frames, 16
     cfm_steps = 64 if args.v2p and args.cfm_steps == 32 else args.cfm_steps
     sd = random_state_dict(cfg, seed=0, device=dev)
@@ -160,6 +176,7 @@ def main():
     log("timed %d steps: %.1f ms/step" % (args.steps, el / args.steps * 1e3))
 
     ms_per_step = el / args.steps * 1e3
+    ph = model.phase_ms()
     frames_per_s = n_clips * T * args.cascade / (el / args.steps)
     evals = cfm_steps - 1
     # algorithmic work per forward per clip at this shape (1040.7 GFLOP GEMM + 75.8 attention)
@@ -170,22 +187,35 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[%d]: %d clip(s)/GPU x %d latent frames x 128 ch, %d-point sway grid = %d CFG "
                                "evaluations (%d DiT forwards), T5 context %d tokens, %s"
-                               % (3 if args.v2p else 1, B, T, cfm_steps, evals, 2 * evals, NC, "V2P roll" if args.v2p else "V2A zero roll"),
+                               % (3 if args.v2p else (4 if args.cascade > 1 else (1 if B == 1 else 2)), B, T, cfm_steps, evals, 2 * evals, NC,
+                                  "V2P roll" if args.v2p else "V2A zero roll"),
                    "clips_per_gpu": B, "global_clips": n_clips, "parallelism": "clip-sharded x%d, 1 all-gather" % world,
                    "hipgraph": not args.no_graph, "side_streams": not args.single_stream, "cascade_passes": args.cascade},
         "per_gpu_mel_frames_per_s": round(frames_per_s / world, 2),
         "clips_per_s": round(n_clips / (el / args.steps), 4),
-        "ms_per_cfg_evaluation": round(ms_per_step / evals, 4),
+        "ms_per_cfg_evaluation": round(ms_per_step / evals / args.cascade, 4),
+        "prepare_ms": round(ph[0], 3), "euler_loop_ms": round(ph[1], 3),     # device-side split of the LAST sample() call of the timed region
     }
 
     if rank == 0 and world == 1:
+        hbm = {}
         if not args.no_batched and B == 1:
             res["batched"] = batched_leg(model, cfg, cfm_steps, args, T, NC, dev)
+            if not args.no_roofline:
+                hbm["clips_8"] = roofline_leg(model, L, args, hbm_only=True)
             log("batched leg done")
         if not args.no_roofline:
-            one_step()                                     # restore the B=1 plan (and its graph) after the batched leg
-            res["roofline"] = roofline_leg(model, L, y0, args)
+            one_step()                                     # restore this run's plan (and its graph) after the batched leg
+            res["roofline"] = roofline_leg(model, L, args)
+            hbm["clips_%d" % B] = res["roofline"].pop("hbm")
+            res["roofline"]["hbm"] = hbm
             log("roofline leg done")
+        if not args.no_parity_mode and T == 750:
+            res["parity_mode"] = parity_mode_leg(v2a_amd, cfg, args, dev)
+            log("parity-mode leg done")
+        if not args.no_configs and B == 1 and not args.v2p and args.cascade == 1:
+            res.update(configs_leg(model, cfg, args, T, NC, dev))
+            log("configs[3] / configs[4] legs done")
         if not args.no_video2roll:
             res["video2roll"] = video2roll_leg(L, args, dev, cpu=not args.no_cpu_baseline)
             log("video2roll leg done")
@@ -328,53 +358,86 @@ def batched_leg(model, cfg, cfm_steps, args, T, NC, dev):
     return {"clips_per_gpu": Bb, "mel_frames_per_s": round(Bb * T / el, 2), "ms_per_step": round(el * 1e3, 2), "clips_per_s": round(Bb / el, 3)}
 
 
-def roofline_leg(model, L, y0, args):
-    """Eager replay of Euler evaluations on ONE stream with every launch bracketed by HIP events recorded on the
-    launch stream (GEMMs: 8 back-to-back launches per event pair, which amortises the ~5 us dispatch gap an eager
-    event pair includes, so avg_launch_us agrees with rocprofv3's kernel durations in profiles/).  `achieved` =
-    algorithmic FLOPs (2*M*N*K per launch) / that time for the GEMM instantiation with the most time per
-    evaluation; the per-kernel table is attached."""
+def _timed_evaluation(model, L, args, reps, shapes=False):
+    """Per-kernel time of ONE Euler evaluation of the model's current plan, kernels one at a time on one stream.
+    Preferred: the evaluation is captured in a hipGraph with an external HIP event recorded in front of every launch
+    (stream = the capture stream, i.e. the stream the kernels run on); falls back to eager event pairs."""
+    from v2a_amd.dit import process_streams
     eng = model.engine()
     p = eng.plan
     y = p["y"]
-    reps = 3
-    side = (p.pop("st", None), p.pop("sf", None))     # kernels one at a time: isolated launch durations
-    prof = L.KernelProfiler(inner=8)
+    side = (p.pop("st", None), p.pop("sf", None))     # no side streams: isolated launch durations
     keep = y.clone()
-    # warm: one untimed eager evaluation
     p["step"].zero_()
-    eng.euler_step(y, args.cfg_strength, False)
-    L.set_profiler(prof)
-    try:
-        for _ in range(reps):
-            p["step"].zero_()
-            eng.euler_step(y, args.cfg_strength, False)
-    finally:
-        L.set_profiler(None)
-    agg = prof.summary()
-    if args.shapes:       # per-shape GEMM table on stderr (tuning aid)
-        prof2 = L.KernelProfiler(shapes=True, inner=8)
-        L.set_profiler(prof2)
+    eng.euler_step(y, args.cfg_strength, False)       # warm
+    torch.cuda.synchronize()
+    how = "hip events between the nodes of a single-stream hipGraph (kernel + launch boundary)"
+    prof = None
+    if not args.eager_roofline:
+        try:
+            prof = L.KernelProfiler(shapes=shapes, external=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=process_streams(model.device)[2], capture_error_mode="thread_local"):
+                L.set_profiler(prof)
+                try:
+                    eng.euler_step(y, args.cfg_strength, False)
+                    prof.close()
+                finally:
+                    L.set_profiler(None)
+            for _ in range(reps):
+                p["step"].zero_()
+                g.replay()
+                torch.cuda.synchronize()
+                prof.collect()
+            del g
+        except Exception as e:                          # external event nodes unsupported: eager brackets instead
+            log("graph-timed evaluation unavailable (%s): falling back to eager event pairs" % str(e)[:120])
+            L.set_profiler(None)
+            torch.cuda.synchronize()
+            prof = None
+    if prof is None:
+        how = "eager HIP event pairs around every launch (includes the dispatch gap)"
+        prof = L.KernelProfiler(shapes=shapes, inner=1)
+        L.set_profiler(prof)
         try:
             for _ in range(reps):
                 p["step"].zero_()
                 eng.euler_step(y, args.cfg_strength, False)
         finally:
             L.set_profiler(None)
-        a2 = prof2.summary()
-        tot2 = sum(a["ms"] for a in a2.values())
-        for k, a in sorted(a2.items(), key=lambda kv: -kv[1]["ms"]):
-            extra = ("%7.1f TF/s" % (a["flops"] / (a["ms"] * 1e-3) / 1e12)) if a["flops"] > 0 and k.startswith("gemm") else ("%7.1f GB/s" % (a["bytes"] / (a["ms"] * 1e-3) / 1e9))
-            log("%-58s n/eval=%3d avg=%7.2f us share=%5.1f%% %s" % (k, a["launches"] // reps, a["ms"] / a["launches"] * 1e3, 100 * a["ms"] / tot2, extra))
+    agg = prof.summary()
     y.copy_(keep)
     p["step"].zero_()
     if side[0] is not None:
         p["st"], p["sf"] = side
+    return agg, how
+
+
+def roofline_leg(model, L, args, hbm_only=False):
+    """`achieved` = algorithmic FLOPs (2*M*N*K per launch) / measured time of the GEMM instantiation with the most time per
+    evaluation; `hbm` = algorithmic bytes / measured time of the memory-bound kernels against the 8 TB/s HBM peak.  The same
+    command under `rocprofv3 --kernel-trace --stats` gives the kernel-only durations committed in profiles/."""
+    reps = 3
+    agg, how = _timed_evaluation(model, L, args, reps)
+    if args.shapes and not hbm_only:       # per-shape GEMM table on stderr (tuning aid)
+        a2, _ = _timed_evaluation(model, L, args, reps, shapes=True)
+        tot2 = sum(a["ms"] for a in a2.values())
+        for k, a in sorted(a2.items(), key=lambda kv: -kv[1]["ms"]):
+            extra = ("%7.1f TF/s" % (a["flops"] / (a["ms"] * 1e-3) / 1e12)) if a["flops"] > 0 and k.startswith("gemm") else ("%7.1f GB/s" % (a["bytes"] / (a["ms"] * 1e-3) / 1e9))
+            log("%-58s n/eval=%3d avg=%7.2f us share=%5.1f%% %s" % (k, a["launches"] // reps, a["ms"] / a["launches"] * 1e3, 100 * a["ms"] / tot2, extra))
+    hbm = {}
+    for k, a in agg.items():
+        if k.startswith(("rmsnorm", "dwconv", "cfg_euler", "rope", "linear_small")):
+            gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            hbm[k] = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
+                      "MB_per_launch": round(a["bytes"] / a["launches"] / 1e6, 3), "achieved_GBs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    if hbm_only:
+        return hbm
     table, tot_ms = {}, sum(a["ms"] for a in agg.values())
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         row = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
                "share": round(a["ms"] / tot_ms, 4)}
-        if a["flops"] > 0 and k.startswith("gemm"):
+        if a["flops"] > 0 and k.startswith(("gemm", "attention")):
             row["tflops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2)
         else:
             row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
@@ -386,15 +449,89 @@ def roofline_leg(model, L, y0, args):
     all_f = sum(a["flops"] for _, a in gem)
     all_ms = sum(a["ms"] for _, a in gem)
     return {"bound": "mfma", "kernel": dom_k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom_k),
+            "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom_k), "timing": how,
             "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2), "launches_per_eval": dom["launches"] // reps,
+            "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
             "all_gemm_tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(all_f / (all_ms * 1e-3) / 1e12 / peak, 4),
-            "eager_eval_kernel_ms": round(tot_ms / reps, 3), "kernels": table}
+            "eval_kernel_ms": round(tot_ms / reps, 3), "kernels": table, "hbm": hbm}
+
+
+def parity_mode_leg(v2a_amd, cfg, args, dev):
+    """configs[1] on the weights / inputs of the committed oracle vector (tests/golden/sample_full.npz: 32-point grid, CFG 2.0):
+    for each compute mode the throughput of sample() AND its max |delta mel| against the CPU restatement over the whole
+    grid (final latents + every grid point on every 8th frame).  The oracle module is used here as the CHECKER only
+    (seeded parameter / input generator of the fixture); nothing of it is timed."""
+    import numpy as np
+    from oracle import e2_cfm_oracle as O
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "sample_full.npz"), allow_pickle=False))
+    P = O.init_params(O.DiTConfig(), 0)
+    y0, text, roll, ctx, cm = O.synthetic_inputs(O.DiTConfig(), 1, 750, nc=16, seed=0)
+    want, want_traj = torch.from_numpy(g["y_steps32"]), torch.from_numpy(g["traj32_sub"])
+    out = {"fixture": "tests/golden/sample_full.npz (oracle, B=1, 32-point sway grid, CFG 2.0)", "tolerance_fp32": 1e-3}
+    for mode in ("fp32", "bf16"):
+        m = v2a_amd.E2TTS(transformer=dict(depth=cfg.depth, dim=cfg.dim, dim_text=cfg.dim_text, heads=cfg.heads, dim_head=cfg.dim_head,
+                                           if_text_modules=True, if_cross_attn=True, if_audio_conv=True, if_text_conv=True),
+                          num_channels=cfg.num_channels, sampling_rate=24000, if_cond_proj_in=False, compute_dtype=mode, device=dev)
+        m.load_state_dict(P, strict=False)
+        kw = dict(y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, steps=32, cfg_strength=2.0,
+                  remove_parallel_component=False, sway_sampling=True, return_raw_output=True)
+        traj = []
+        got = m.sample(torch.zeros(1, 750, 128), trajectory_out=traj, **kw)          # also the warm-up
+        torch.cuda.synchronize()
+        n = 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m.sample(torch.zeros(1, 750, 128), **kw)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / n
+        err = (got[0].cpu() - want).abs()
+        terr = (torch.stack([t[0, ::8].cpu() for t in traj]) - want_traj).abs().amax(dim=(1, 2))
+        out[mode] = {"mel_frames_per_s": round(750 / el, 2), "ms_per_step": round(el * 1e3, 3),
+                     "max_abs_delta_mel": float("%.3e" % float(err.max())), "mean_abs_delta_mel": float("%.3e" % float(err.mean())),
+                     "max_abs_delta_mel_over_grid": float("%.3e" % float(terr.max())), "meets_1e-3": bool(float(err.max()) < 1e-3 and float(terr.max()) < 1e-3)}
+        del m
+        torch.cuda.empty_cache()
+    return out
+
+
+def configs_leg(model, cfg, args, T, NC, dev):
+    """Supplementary: BASELINE configs[3] (V2P: non-zero piano roll, the CLI's 64-point grid, src/inference_v2p.py:183) and
+    configs[4] (3 cascaded 32-point passes -- defined by this build, the reference has no CoT-guidance code, SURVEY 8d -- at
+    the per-GPU share of B=32 on 8 GPUs: 4 clips)."""
+    from v2a_amd.synth import synthetic_conditioning
+    out = {}
+    def run(Bc, steps, piano, passes, seed):
+        y0, text, roll, ctx, cm = synthetic_conditioning(cfg, Bc, T, NC, seed=seed, piano=piano, device=dev)
+        cond = torch.empty(Bc, T, cfg.num_channels, device=dev)
+        lens = torch.full((Bc,), T, dtype=torch.long)
+        def once():
+            for _ in range(passes):
+                o = model.sample(cond, y0=y0, text_embed=text, context=ctx, context_mask=cm.cpu(), frames_embed=roll, lens=lens, duration=lens,
+                                 steps=steps, cfg_strength=args.cfg_strength, remove_parallel_component=False, sway_sampling=True, return_raw_output=True)
+            return o
+        once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            o = once()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / n
+        assert bool(torch.isfinite(o).all())
+        step_ctr = int(model.engine().plan["step"].item())
+        return el, step_ctr
+    el, ctr = run(1, 64, True, 1, 311)
+    out["v2p"] = {"workload": "configs[3]: 1 clip, V2P roll, 64-point grid (63 CFG evaluations)", "ms_per_step": round(el * 1e3, 2),
+                  "mel_frames_per_s": round(T / el, 2), "step_counter": ctr}
+    el, ctr = run(4, 32, False, 3, 312)
+    out["cascade"] = {"workload": "configs[4]: 4 clips/GPU x 3 cascaded 32-point passes (synthetic definition)", "ms_per_step": round(el * 1e3, 2),
+                      "mel_frames_per_s": round(4 * 3 * T / el, 2), "clips_per_s": round(4 / el, 3)}
+    return out
 
 
 def pmc_traffic(kernel_key):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc{1,2}_summary.csv; FETCH_SIZE and WRITE_SIZE collected in separate passes, KB units,
+    (profiles/ files named in PMC_FILES; FETCH_SIZE and WRITE_SIZE collected in separate passes, KB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC collection cannot run inside
     the timed bench, so this is the recorded figure for the same kernel instantiation, or None."""
     import csv
@@ -411,17 +548,18 @@ def pmc_traffic(kernel_key):
                 k = r["kernel"]
                 if "gemm_bf16_dma_kernel" not in k:
                     continue
-                ok = k.startswith("gemm_bf16_dma_kernel<%s, %s" % (epi[parts[2]], "float" if tag_o == "f" else "__bf16")) or                      k.startswith("gemm_bf16_dma_kernel<%s%s" % (tag_e, tag_o))
+                ok = (k.startswith("gemm_bf16_dma_kernel<%s, %s" % (epi[parts[2]], "float" if tag_o == "f" else "__bf16"))
+                      or k.startswith("gemm_bf16_dma_kernel<%s%s" % (tag_e, tag_o)))
                 if ok and (best is None or int(r["dispatches"]) > int(best["dispatches"])):
                     best = r
             return best
-        f, w = pick(rows("r01_pmc1_summary.csv")), pick(rows("r01_pmc2_summary.csv"))
+        f, w = pick(rows(PMC_FILES[0])), pick(rows(PMC_FILES[1]))
         if f is None or w is None:
             return None
         fetch = float(f["FETCH_SIZE"]) * 1024 * 2 / int(f["dispatches"])
         write = float(w["WRITE_SIZE"]) * 1024 / int(w["dispatches"])
         return {"bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
-                "source": "profiles/r01_pmc1_summary.csv + r01_pmc2_summary.csv (rocprofv3 --pmc, separate passes; FETCH_SIZE x2)"}
+                "source": "profiles/%s + %s (rocprofv3 --pmc, separate passes; FETCH_SIZE x2)" % PMC_FILES}
     except Exception:
         return None
 
@@ -447,10 +585,10 @@ def cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T):
     got = one_step(steps=s)[:1].float().cpu()
     err = (got - ref).abs()
     return {"cpu_baseline": {"value": round(T / full, 3), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                             "sample": "B=1, %d-point grid (%d of 31 CFG evaluations, %.1f s CPU), extrapolated linearly in evaluations; "
-                                       "CPU restatement of the reference in plain torch fp32" % (s, s - 1, cpu_s),
+                             "sample": "B=1, steps=%d (%d of 31 CFG evaluations = %d forwards, %.1f s CPU), extrapolated linearly in evaluations; "
+                                       "CPU restatement of the reference in plain torch fp32" % (s, s - 1, 2 * (s - 1), cpu_s),
                              "s_per_cfg_evaluation": round(per_eval, 3)},
-            "parity": {"mode": args.dtype, "sample": "same %d-point grid, B=1" % s, "max_abs_delta_mel": round(float(err.max()), 6),
+            "parity": {"mode": args.dtype, "sample": "same steps=%d run, B=1 (the 32-point grid is in parity_mode)" % s, "max_abs_delta_mel": round(float(err.max()), 6),
                        "mean_abs_delta_mel": round(float(err.mean()), 7)}}
 
 

@@ -15,6 +15,9 @@ run() {  # name timeout cmd...
 }
 for s in "$@"; do
   case $s in
+    rowbench) TAILN=10 run rowbench 300 python scripts/microbench_rowops.py ;;
+    kdw) run kdw 300 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "dwconv or rmsnorm" ;;
+    extev) TAILN=12 run extev 120 python scripts/probes/ext_event_probe.py ;;
     k8p) run k8p 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "8phase" ;;
     probe) TAILN=40 run probe 600 python scripts/gemm_probe.py ${PROBE_ARGS:-} ;;
     probe_geglu) TAILN=40 run probe_geglu 600 python scripts/gemm_probe.py --epi geglu 1564x8192x1024 1564x10240x1280 1564x4096x512 12512x8192x1024 ;;
@@ -27,7 +30,11 @@ for s in "$@"; do
     full) TAILN=40 run full 900 python -m pytest tests/test_full_shape_gpu.py -q -m gpu --tb=short -s ;;
     alltests) run alltests 1100 python -m pytest tests -q -m gpu -x --tb=short ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
-    bench) run bench 900 python bench.py --steps 3 --warmup 1 ;;
+    bench) TAILN=4 run bench 900 python bench.py --steps 5 --warmup 2 ;;
+    ab8) for v in "0 0" "1 200" "1 80"; do set -- $v
+           TAILN=0 run ab8_$1_$2 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --gemm-8phase $1 --gemm-8phase-min-tiles $2
+           echo "--- 8phase=$1 min_tiles=$2: $(grep -o '"value": [0-9.]*' gpurun_out/ab8_$1_$2.log) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/ab8_$1_$2.log | head -1)"
+         done ;;
     bench_nocpu) run bench_nocpu 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_shapes) run bench_shapes 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --shapes ;;
     bench8) run bench8 600 python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline ;;
@@ -43,7 +50,8 @@ for s in "$@"; do
              TAILN=0 run batch_$b 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --clips-per-gpu $b
              echo "--- B=$b: $(grep -E 'timed' gpurun_out/batch_$b.log) $(grep -o '"value": [0-9.]*' gpurun_out/batch_$b.log)"
            done ;;
-    shapes8) run shapes8 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --shapes --single-stream --clips-per-gpu 8 ;;
+    shapes8) TAILN=45 run shapes8 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --shapes --single-stream --clips-per-gpu 8 --no-parity-mode --no-configs --no-video2roll --no-vocoder ;;
+    shapes1) TAILN=45 run shapes1 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --shapes --single-stream --no-batched --no-parity-mode --no-configs --no-video2roll --no-vocoder ;;
     configs) TAILN=2 run cfg_v2p 300 python bench.py --steps 2 --warmup 1 --v2p --no-cpu-baseline --no-roofline --no-batched
              TAILN=2 run cfg_cascade 300 python bench.py --steps 2 --warmup 1 --cascade 3 --clips-per-gpu 4 --no-cpu-baseline --no-roofline --no-batched ;;
     big) for t in 0 1; do

@@ -66,8 +66,10 @@ def test_adaptive_rmsnorm_golden(L, small, golden):
 
 
 # -------------------------------------------------------------------------------- dwconv
-@pytest.mark.parametrize("N,d,lens", [(44, 128, [44, 30]), (782, 512, None), (7, 64, [7, 3]), (100, 1280, [100, 33])])
-def test_dwconv(L, N, d, lens):
+@pytest.mark.parametrize("tn", [4, 8])
+@pytest.mark.parametrize("N,d,lens", [(44, 128, [44, 30]), (782, 512, None), (7, 64, [7, 3]), (100, 1280, [100, 33]), (782, 1024, [782, 1])])
+def test_dwconv(L, N, d, lens, tn):
+    """Both position-tile sizes of the kernel (4 / 8 outputs per wave pass); edge tiles, masked tails, a 1-frame clip."""
     B = 2
     x = torch.randn(B, N, d, generator=_g(N))
     w = torch.randn(d, 1, 31, generator=_g(N + 1)) / math.sqrt(31)
@@ -76,7 +78,11 @@ def test_dwconv(L, N, d, lens):
     ref = O.depthwise_conv(x, w, bias, mask) + x
     out = torch.empty(B, N, d, device=DEV)
     ld = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=DEV)
-    L.dwconv(x.to(DEV), out, w[:, 0, :].t().contiguous().to(DEV), bias.to(DEV), B=B, N=N, d=d, ksize=31, lens=ld)
+    L.set_tuning(dwconv_rows_per_wave=tn)
+    try:
+        L.dwconv(x.to(DEV), out, w[:, 0, :].t().contiguous().to(DEV), bias.to(DEV), B=B, N=N, d=d, ksize=31, lens=ld)
+    finally:
+        L.set_tuning()
     torch.testing.assert_close(out.cpu(), ref, atol=2e-5, rtol=1e-5)
 
 

@@ -47,6 +47,7 @@ struct GemmTuning {
   int min_tiles_8phase;  // ... when the problem has at least this many 256x256 tiles
 };
 extern GemmTuning g_gemm_tuning;
+extern int g_dwconv_rows_per_wave;   // 4 or 8 (v2a_set_tuning)
 
 // 256x256 8-phase kernel (gemm_8phase.hip)
 int launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);

@@ -4,6 +4,8 @@
 // All loads/stores are 16 B per lane on the channel-contiguous (B, N, d) layout.
 #include "v2a_common.h"
 
+namespace v2a_detail { extern int g_dwconv_rows_per_wave; }
+
 thread_local char v2a_err_buf[512] = {0};
 
 extern "C" int v2a_abi_version(void) { return 3; }
@@ -62,15 +64,22 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // Depthwise conv (k taps along N) + bias + SiLU + mask + residual.
 // Block = 4 waves = 4 consecutive position tiles of TN outputs for the same 256 channels (a lane owns 4 channels).
-// The k x 256 tap weights are fetched ONCE per block into LDS (8 float4 per thread instead of 31 per wave); every
-// thread then issues all TN + k - 1 input rows it needs back to back (one memory latency instead of one per row)
-// and sweeps the taps with the weights read from LDS.  Algorithmic traffic: 4*d B in + 4*d B out per position.
+// The k x 256 tap weights are fetched ONCE per block into LDS, zero-padded to a multiple of TN taps.  Input row i of a tile
+// feeds output t through tap i - t, so a wave walks its rows in groups of TN with a window of TN taps in registers: row
+// 8g + r brings tap 8g + r into slot r and output t multiplies slot (r - t) mod TN -- taps before the kernel start are the
+// zero-initialised window, taps past its end the zero padding, so the inner body has no conditions.  A real (not unrolled)
+// loop over row groups keeps the live set at acc + window + two row groups: three waves per SIMD.  (The first version held
+// all 31 taps in registers: 396 VGPRs, one wave per SIMD, and at 8 clips per GPU it ran VALU-bound at 1.4 TB/s with
+// nothing to overlap a block's load phase with.)  Algorithmic traffic: 4*d B in + 4*d B out per position.
 // ------------------------------------------------------------------------------------------
 template <int KS, int TN>
-__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                     const float* __restrict__ wt, const float* __restrict__ bias,
-                                                     int B, int N, int d, const int32_t* len) {
-  __shared__ __attribute__((aligned(16))) float wl[KS * 256];
+__global__ __launch_bounds__(256, 3) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                        const float* __restrict__ wt, const float* __restrict__ bias,
+                                                        int B, int N, int d, const int32_t* len) {
+  constexpr int HALF = KS / 2;
+  constexpr int NG = (TN + KS - 1 + TN - 1) / TN;        // row groups of TN rows
+  constexpr int TAPS = NG * TN;                          // taps incl. zero padding
+  __shared__ __attribute__((aligned(16))) float wl[TAPS * 256];
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so flat id % 8 labels the L2 a block will
   // use.  Give each label a contiguous range of position tiles (all channel blocks of a tile together): the k-1
   // halo rows a tile shares with its neighbours then hit in that XCD's L2 instead of being fetched over the
@@ -87,53 +96,69 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
   const int c4 = cblk * 64 + lane;                       // float4 channel group of this lane
   const bool cok = c4 * 4 < d;
   const int cc = cok ? c4 : d / 4 - 1;                   // idle lanes shadow a valid channel group, only the store is masked
-  for (int i = threadIdx.x; i < KS * 64; i += 256) {     // taps x 64 float4 of this channel block, once per block
+  for (int i = threadIdx.x; i < TAPS * 64; i += 256) {   // taps x 64 float4 of this channel block, once per block
     const int tap = i >> 6;
     int ch4 = cblk * 64 + (i & 63);
     ch4 = ch4 * 4 < d ? ch4 : d / 4 - 1;
-    *reinterpret_cast<f32x4*>(wl + i * 4) = *reinterpret_cast<const f32x4*>(wt + (int64_t)tap * d + 4 * ch4);
+    f32x4 w = {0.f, 0.f, 0.f, 0.f};
+    if (tap < KS) w = *reinterpret_cast<const f32x4*>(wt + (int64_t)tap * d + 4 * ch4);
+    *reinterpret_cast<f32x4*>(wl + i * 4) = w;
   }
   __syncthreads();
-  f32x4 w[KS];
-#pragma unroll
-  for (int j = 0; j < KS; ++j) w[j] = *reinterpret_cast<const f32x4*>(wl + (j * 64 + lane) * 4);
 
   const int n0 = (ptile * 4 + wave) * TN;                // wave-uniform
   const int L = len ? min(len[b], N) : N;
-  constexpr int HALF = KS / 2;
   const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * cc);
-  f32x4 acc[TN];
+  f32x4 acc[TN], win[TN];
 #pragma unroll
-  for (int t = 0; t < TN; ++t) acc[t] = bv;
+  for (int t = 0; t < TN; ++t) {
+    acc[t] = bv;
+    win[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   // row base is wave-uniform (SGPR), the lane contributes a constant 32-bit byte offset: no vector address math
   const char* xrow0 = reinterpret_cast<const char*>(x + (int64_t)b * N * d);
   const uint32_t loff = (uint32_t)cc * 16u;
-  f32x4 center[TN];
-  // input position n0 - HALF + i contributes to output t with tap j = i - t.  Straight-line code: every row is
-  // loaded (clamped into the sequence) and scaled by a 0/1 wave-uniform factor instead of being branched around,
-  // so all loads of the tile are in flight together and the FMA stream has no control flow.  (Measured variants:
-  // per-row branches 14.1 us, this form 10.0 us, chunked / register-capped forms spill and are slower.)
+  const float* wlane = wl + lane * 4;
+  f32x4 rowsA[TN], rowsB[TN];
+  auto load_group = [&](int g, f32x4 (&dst)[TN]) {
 #pragma unroll
-  for (int i = 0; i < TN + KS - 1; ++i) {
-    const int pos = n0 - HALF + i;                       // wave-uniform
-    const int pc = min(max(pos, 0), N - 1);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)pc * d * 4 + loff);
-    if (i >= HALF && i < HALF + TN) center[i - HALF] = v;   // unmasked x for the residual (x3:1082: conv(x, mask) + x)
-    const float f = (pos >= 0 && pos < L) ? 1.0f : 0.0f;    // zero padding and masked rows contribute nothing
-    const f32x4 vm = {v[0] * f, v[1] * f, v[2] * f, v[3] * f};
+    for (int r = 0; r < TN; ++r) {
+      const int pc = min(max(n0 - HALF + g * TN + r, 0), N - 1);   // clamped into the sequence; the 0/1 factor below zeroes it
+      dst[r] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)pc * d * 4 + loff);
+    }
+  };
+  auto group = [&](int g, const f32x4 (&cur)[TN]) {
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      const int j = i - t;
-      if (j >= 0 && j < KS) {
-        acc[t][0] += w[j][0] * vm[0];
-        acc[t][1] += w[j][1] * vm[1];
-        acc[t][2] += w[j][2] * vm[2];
-        acc[t][3] += w[j][3] * vm[3];
+    for (int r = 0; r < TN; ++r) {
+      win[r] = *reinterpret_cast<const f32x4*>(wlane + (g * TN + r) * 256);
+      const int pos = n0 - HALF + g * TN + r;            // wave-uniform
+      // zero padding and masked rows contribute nothing: a scalar branch around the row's FMAs (a 0/1 factor on the row
+      // costs 4 multiplies per row and made the vectoriser pack values ACROSS rows, waiting on every load right after
+      // its issue); whole-vector expressions keep the arithmetic as v_pk_fma_f32
+      if (pos >= 0 && pos < L) {
+        const f32x4 v = cur[r];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = win[(r - t + TN) % TN] * v + acc[t];
       }
+    }
+  };
+  load_group(0, rowsA);
+#pragma unroll 1
+  for (int g = 0; g < NG; g += 2) {
+    if (g + 1 < NG) load_group(g + 1, rowsB);
+    group(g, rowsA);
+    if (g + 1 < NG) {
+      if (g + 2 < NG) load_group(g + 2, rowsA);
+      group(g + 1, rowsB);
     }
   }
   if (!cok) return;
   char* orow0 = reinterpret_cast<char*>(out + (int64_t)b * N * d);
+  // the unmasked centre rows for the residual (x3:1082: conv(x, mask) + x) come back from L1/L2 here rather than
+  // being held in 32 registers through the tap loop
+  f32x4 center[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) center[t] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)min(n0 + t, N - 1) * d * 4 + loff);
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int n = n0 + t;
@@ -398,10 +423,14 @@ extern "C" int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, in
   const int vpl = (d / 4 + 63) / 64;
 #define V2A_RMS(OT, V) \
   hipLaunchKernelGGL((rmsnorm_kernel<OT, V>), grid, block, 0, s, x, ldx, (OT*)y, ldy, rows, d, gamma, step, gss, gbs, rpb)
+  // exact float4-per-lane counts for the widths of the path (512 -> 2, 1024 -> 4, 1280 -> 5): with the 8-wide instantiation
+  // d = 1280 carried three dead, bounds-checked vectors per lane and streamed 2.9 TB/s against 5.1 TB/s at d = 1024
   if (y_dtype == V2A_F32) {
-    if (vpl <= 1) V2A_RMS(float, 1); else if (vpl <= 2) V2A_RMS(float, 2); else if (vpl <= 4) V2A_RMS(float, 4); else V2A_RMS(float, 8);
+    if (vpl <= 1) V2A_RMS(float, 1); else if (vpl <= 2) V2A_RMS(float, 2); else if (vpl <= 3) V2A_RMS(float, 3); else if (vpl <= 4) V2A_RMS(float, 4);
+    else if (vpl <= 5) V2A_RMS(float, 5); else if (vpl <= 6) V2A_RMS(float, 6); else V2A_RMS(float, 8);
   } else {
-    if (vpl <= 1) V2A_RMS(bf16_t, 1); else if (vpl <= 2) V2A_RMS(bf16_t, 2); else if (vpl <= 4) V2A_RMS(bf16_t, 4); else V2A_RMS(bf16_t, 8);
+    if (vpl <= 1) V2A_RMS(bf16_t, 1); else if (vpl <= 2) V2A_RMS(bf16_t, 2); else if (vpl <= 3) V2A_RMS(bf16_t, 3); else if (vpl <= 4) V2A_RMS(bf16_t, 4);
+    else if (vpl <= 5) V2A_RMS(bf16_t, 5); else if (vpl <= 6) V2A_RMS(bf16_t, 6); else V2A_RMS(bf16_t, 8);
   }
 #undef V2A_RMS
   return v2a_check_launch("v2a_rmsnorm");
@@ -413,12 +442,13 @@ extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float*
   V2A_REQUIRE(x != out, "v2a_dwconv: out must not alias x (halo reads)");
   V2A_REQUIRE(ksize == 31, "v2a_dwconv: kernel_size %d (only 31 is built, x3:726)", ksize);
   V2A_REQUIRE(d % 4 == 0 && B > 0 && N > 0, "v2a_dwconv: B=%d N=%d d=%d", B, N, d);
-  constexpr int TN = 8;
+  const int TN = v2a_detail::g_dwconv_rows_per_wave;
   const int cb = (d / 4 + 63) / 64;                      // 256-channel blocks
   // grid.y counts groups of 4 position tiles, padded to a multiple of 8 so every XCD label owns a whole range
   const int P = (N + 4 * TN - 1) / (4 * TN);
   dim3 grid(cb, ((P + 7) / 8) * 8, B), block(256);
-  hipLaunchKernelGGL((dwconv_kernel<31, TN>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
+  if (TN == 8) hipLaunchKernelGGL((dwconv_kernel<31, 8>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
+  else hipLaunchKernelGGL((dwconv_kernel<31, 4>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
   return v2a_check_launch("v2a_dwconv_silu_residual");
 }
 
