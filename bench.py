@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="grid points of the bounded CPU sample (SURVEY 8d: steps=4)")
     ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered, 2 lock-step)")
     ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
+    ap.add_argument("--gemm-force-tile", type=int, default=-1, help="v2a_set_tuning: one tile configuration for every bf16 GEMM (experiment)")
+    ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
+    ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the supplementary configs[3] (V2P) and configs[4] (cascade) legs")
     ap.add_argument("--eager-roofline", action="store_true", help="time kernels with eager event pairs instead of events between graph nodes")
@@ -113,8 +116,9 @@ def main():
     from v2a_amd import _lib as L
     from v2a_amd.synth import random_state_dict, synthetic_conditioning
 
-    if args.gemm_8phase >= 0:
-        L.set_tuning(eight_phase=args.gemm_8phase, eight_phase_min_tiles=args.gemm_8phase_min_tiles)
+    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0:
+        L.set_tuning(force_tile=args.gemm_force_tile, eight_phase=(args.gemm_8phase if args.gemm_8phase >= 0 else None),
+                     eight_phase_min_tiles=args.gemm_8phase_min_tiles)
     cfg = v2a_amd.DiTConfig()
     if args.clips_per_gpu <= 0:
         args.clips_per_gpu = 1 if world == 1 else 8
@@ -129,6 +133,11 @@ def main():
     model.load_state_dict(sd, strict=False)
     del sd
     model.engine().multi_stream = not args.single_stream
+    if args.single_stream:
+        model.engine().side_tile = -1
+    elif args.side_tile >= -1:
+        model.engine().side_tile = args.side_tile
+    model.engine().cross_on_main = args.cross_on_main
     log("weights packed")
     y0, text, roll, ctx, cm = synthetic_conditioning(cfg, B, T, NC, seed=1000 + rank, piano=args.v2p, device=dev)
     cm = cm.cpu()

@@ -103,6 +103,11 @@ typedef struct v2a_gemm_args {
   const int32_t* a_row_offset;
   const int32_t* a_ktile_offset;
   const int32_t* out_row_offset;
+  /* 0 = the library picks the tile shape for the fastest stand-alone launch.  k + 1 = use LDS-DMA tile configuration k of
+   * v2a_tuning.gemm_force_tile for THIS call (bf16 x bf16 only).  The sampler passes 1 (128x256 tiles, one workgroup per CU) for
+   * the text / frames streams: their GEMMs run beside the audio stream's, and few fat workgroups that own whole CUs disturb
+   * the critical path less than many small ones spread over every CU (+3.5 % end to end, measured). */
+  int32_t tile_hint;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);

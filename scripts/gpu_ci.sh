@@ -15,6 +15,18 @@ run() {  # name timeout cmd...
 }
 for s in "$@"; do
   case $s in
+    trace) rm -rf /tmp/trace; TAILN=3 run trace 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace -- python bench.py --steps 1 --warmup 1 --cfm-steps 8 --no-cpu-baseline --no-roofline --no-batched --no-parity-mode --no-configs --no-video2roll --no-vocoder
+           python scripts/timeline_summary.py /tmp/trace > gpurun_out/timeline.txt 2>&1; tail -n 90 gpurun_out/timeline.txt ;;
+    side) SW=${SIDE_SWEEP:-"-1:-1 0:-1 5:-1 6:-1 0:0 6:0"}
+         for v in $SW; do
+           st=${v%%:*}; mt=${v##*:}
+           TAILN=0 run side_${st}_${mt} 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --side-tile $st --gemm-force-tile $mt
+           echo "--- side tile $st main tile $mt: $(grep -o '"value": [0-9.]*' gpurun_out/side_${st}_${mt}.log)"
+         done ;;
+    cross) for v in "" "--cross-on-sides"; do
+           TAILN=0 run cross_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --side-tile 0 $v
+           echo "--- side tile 0 $v: $(grep -o '"value": [0-9.]*' gpurun_out/cross_x.log)"
+         done ;;
     rowbench) TAILN=10 run rowbench 300 python scripts/microbench_rowops.py ;;
     kdw) run kdw 300 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "dwconv or rmsnorm" ;;
     extev) TAILN=12 run extev 120 python scripts/probes/ext_event_probe.py ;;

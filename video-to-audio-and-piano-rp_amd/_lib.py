@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("gate_step_stride", C.c_int64), ("gate_batch_stride", C.c_int64), ("rows_per_batch", C.c_int32),
         ("rope_table", C.c_void_p), ("rope_cols", C.c_int32), ("rope_pos_offset", C.c_int32), ("relu", C.c_int32),
         ("a_row_offset", C.c_void_p), ("a_ktile_offset", C.c_void_p), ("out_row_offset", C.c_void_p),
+        ("tile_hint", C.c_int32),
     ]
 
 
@@ -257,7 +258,7 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
-         a_row_offset=None, a_ktile_offset=None, out_row_offset=None):
+         a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
     g = GemmArgs()
     for i, (t, lda, k) in enumerate(a_segs):
@@ -288,6 +289,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
     g.relu = 1 if relu else 0
     g.a_row_offset, g.a_ktile_offset, g.out_row_offset = _p(a_row_offset), _p(a_ktile_offset), _p(out_row_offset)
+    g.tile_hint = tile_hint if compute == BF16 and g.a_dtype == BF16 and epilogue != EPI_SIGMOID else 0
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")

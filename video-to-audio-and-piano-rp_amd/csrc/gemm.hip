@@ -496,7 +496,21 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   // bf16 x bf16: LDS-DMA kernel; tile shape by how many workgroups the problem yields (256 CUs)
   auto ntiles = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
   // wide outputs: 256x256 tile with the phase-interleaved K loop (gemm_8phase.hip) once the problem yields enough tiles
+  V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 7, "v2a_gemm: tile_hint %d", a->tile_hint);
   const bool dense = !a->a_row_offset && !a->out_row_offset && p.vec_epi;
+  if (a->tile_hint > 0 && tune.force_tile < 0) {
+    if (a->tile_hint == 7) {
+      V2A_REQUIRE(dense, "v2a_gemm: tile_hint 7 (256x256 8-phase) needs dense rows and 16-byte aligned epilogue operands");
+      return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
+    }
+    switch (a->tile_hint - 1) {
+      case 5: return dispatch_dma<256, 256, 2, 4, 2>(a, p, s);
+      case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);
+      case 1: return dispatch_dma<128, 128, 2, 2>(a, p, s);
+      case 2: return dispatch_dma<128, 64, 2, 2>(a, p, s);
+      default: return dispatch_dma<64, 64, 2, 2>(a, p, s);
+    }
+  }
   if (tune.force_tile == 6 || (tune.force_tile < 0 && tune.use_8phase && dense && a->N >= 2048 && ntiles(256, 256) >= tune.min_tiles_8phase))
     return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
   int cfg;

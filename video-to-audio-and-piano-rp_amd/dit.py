@@ -198,6 +198,12 @@ class DiTEngine:
                  zero_masked_queries: bool = True, softclamp: float = 50.0, multi_stream: bool = True):
         assert compute in ("bf16", "fp32")
         self.multi_stream = multi_stream
+        # GEMMs of the text / frames blocks: tile configuration 0 (128x256, one 144 KB workgroup per CU) when they run beside the
+        # audio block on side streams -- few fat workgroups that own whole CUs disturb the critical path less than many small
+        # ones spread over every CU (+3.5 % end to end); -1 = the library's stand-alone choice
+        self.side_tile = 0 if multi_stream else -1
+        # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
+        self.cross_on_main = False
         # RoPE rides in the QKV GEMM epilogue when pairs are lane-local (interleaved layout, bf16 DMA kernel)
         self._fuse_rope = compute == "bf16" and rope_layout == "interleaved"
         assert cfg.dim_head == 64, "kernels are built for dim_head = 64 (x3:717)"
@@ -227,7 +233,7 @@ class DiTEngine:
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
         p = dict(key=key, B=B, Bt=Bt, T=T, N=N, nc=nc, S=S, rows=rows, cfg_mode=cfg_mode)
         D, Dt, Df = c.dim, c.dim_text, c.dim_frames
-        p["xA"], p["xB"] = e(Bt, N, D), e(Bt, N, D)
+        p["xA"], p["xB"], p["xS"] = e(Bt, N, D), e(Bt, N, D), e(Bt, N, D)
         p["skips"] = [e(Bt, N, D) for _ in range(c.depth // 2)]
         p["tA"], p["tB"], p["t0"], p["tL0"] = e(Bt, N, Dt), e(Bt, N, Dt), e(Bt, N, Dt), e(Bt, N, Dt)
         p["fA"], p["fB"], p["f0"], p["fL0"] = e(Bt, N, Df), e(Bt, N, Df), e(Bt, N, Df), e(Bt, N, Df)
@@ -302,16 +308,16 @@ class DiTEngine:
             return dict(gate=tab, gate_batch_stride=ss, rows_per_batch=p["N"])
         return dict(gate=tab, step=p["step"], gate_step_stride=ss, rows_per_batch=p["N"])
 
-    def _self_attn(self, A: _Attn, x, s, nseq, d, out_kw):
+    def _self_attn(self, A: _Attn, x, s, nseq, d, out_kw, in_kw={}):
         """x += epilogue(to_out(attend(rope(q), rope(k), v) * sigmoid(gate))), operand hn_s already normed."""
         p = self.plan
         N, rows = p["N"], nseq * p["N"]
         hn, qkv, ao = p[f"hn_{s}"], p[f"qkv_{s}"], p[f"ao_{s}"]
         if self._fuse_rope:       # RoPE of the q and k heads inside the QKV GEMM epilogue
             L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad,
-                   rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N)
+                   rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **in_kw)
         else:
-            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad)
+            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad, **in_kw)
             L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
                    table=p["rope"], layout=self.rope_layout)
         es = qkv.element_size()
@@ -325,12 +331,12 @@ class DiTEngine:
                     scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.cdc)
         L.gemm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, compute=self.cdc, resid=x, ldo=d, ldr=d, **out_kw)
 
-    def _ff(self, Fw: _FF, x, s, nseq, d, out_kw):
+    def _ff(self, Fw: _FF, x, s, nseq, d, out_kw, in_kw={}):
         p = self.plan
         rows = nseq * p["N"]
         hn, ffh = p[f"hn_{s}"], p[f"ffh_{s}"]
         L.gemm([(hn, d, d)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, compute=self.cdc, epilogue=L.EPI_GEGLU,
-               bias=Fw.b1, ldo=Fw.inner)
+               bias=Fw.b1, ldo=Fw.inner, **in_kw)
         L.gemm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, compute=self.cdc, bias=Fw.b2, resid=x,
                ldo=d, ldr=d, out_bf16=self._sh(x), **out_kw)
 
@@ -340,11 +346,12 @@ class DiTEngine:
         N, rows = p["N"], nseq * p["N"]
         lens = p["seq_len"] if p["ragged"] else None
         cv = ly[f"{s}_conv"]
+        hint = dict(tile_hint=self.side_tile + 1)
         L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
         self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g1"])
-        self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID))
+        self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
         self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g2"])
-        self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID))
+        self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
@@ -429,9 +436,8 @@ class DiTEngine:
         their own stream; the cross-condition reads the PRE-update x, text, frames; the audio block A_i needs
         the cross-conditioned x.  Hence T_{i+1} and F_{i+1} run beside A_i.  With side streams this is
         expressed by events (captured as hipGraph edges); without them everything is issued in order on
-        the current stream.  Events per layer: side blocks done (eT,eF), main's cross GEMM done (eX: the
-        side streams may then overwrite the text/frames buffers it read), side cross GEMMs done (eXt,eXf:
-        main may then overwrite x / its bf16 shadow)."""
+        the current stream.  Two hand-offs per layer: side blocks done (eT, eF -> main's cross-condition GEMMs of the
+        next layer) and the three cross-condition GEMMs done (eX -> the side streams may start their next block)."""
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
         D, Dt, Df = c.dim, c.dim_text, c.dim_frames
@@ -472,49 +478,49 @@ class DiTEngine:
                     if e is not None:
                         stream.wait_event(e)
 
-        eA = rec(main)                  # x (embed output) is ready; also forks the side streams into the capture
         eT = eF = None                  # layer 0's side blocks were hoisted into prepare()
+        eA = rec(main) if not self.cross_on_main else None      # x of layer 0 (embed output) is ready; forks the side streams
         for i, ly in enumerate(W.layers):
             last = i == c.depth - 1
-            # main: cross condition onto the audio stream (x3:686-702); reads x, text, frames of this layer
+            # Cross condition (x3:686-702): three GEMMs, each reading the PRE-update x, text, frames of this layer.  x of this
+            # layer (xc) is never overwritten during the layer -- the conv output goes to the other buffer -- so nothing has to
+            # wait for the side streams to have read it.  (A kernel trace of the first version showed the main stream idle for
+            # ~100 us per layer across two cross-stream hand-offs, each costing 10-50 us of queue-to-queue latency.)
             wait(main, eT, eF)
             xn = p["skips"][i] if i < half else xo
             ax, at_, af_ = self._opnd(xc), self._opnd(tc_), self._opnd(fc_)
             L.gemm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D, compute=self.cdc,
                    epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn))
-            eX = rec(main)
-            eXt = eXf = None
             if not last:
                 nxt = W.layers[i + 1]
-                # side streams: own cross-condition GEMM, then the NEXT layer's block
-                with _On(st):
-                    wait(st, eA)                                   # x of this layer (eT is on this stream already)
+                hint = self.side_tile + 1 if (multi and not self.cross_on_main) else 0
+                def cross_t():
                     L.gemm([(ax, D, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt, compute=self.cdc,
-                           epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt)
-                    eXt = rec(st)
-                    wait(st, eX)                                   # main has read this layer's text buffer
-                    self._side_block(nxt, "t", tbuf[0], tbuf[1], Bt, Dt)
-                    eT = rec(st)
-                with _On(sf):
-                    wait(sf, eA)
+                           epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt, tile_hint=hint)
+                def cross_f():
                     L.gemm([(ax, D, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df, compute=self.cdc,
-                           epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df)
-                    eXf = rec(sf)
-                    wait(sf, eX)
-                    self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df)
-                    eF = rec(sf)
-                tc_, fc_ = tbuf[1], fbuf[1]
-            # main may overwrite x (and its shadow) only after the side cross GEMMs have read it
-            wait(main, eXt, eXf)
-            # U-Net skip (x3:1108-1117).  First half: the cross-condition output buffer IS the saved skip;
-            # xc is free again and takes the conv output.  Second half: skip_proj(cat(x, skip)) -> xc,
-            # conv -> xo, then swap.
+                           epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df, tile_hint=hint)
+                if self.cross_on_main or not multi:
+                    cross_t()
+                    cross_f()
+                    eX = rec(main)
+                else:
+                    with _On(st):
+                        wait(st, eA)
+                        cross_t()
+                    with _On(sf):
+                        wait(sf, eA)
+                        cross_f()
+                    eX = None
+            # U-Net skip (x3:1108-1117).  First half: the cross-condition output buffer IS the saved skip.  Second half:
+            # skip_proj(cat(x, skip)) -> spare buffer.  The conv output (and the whole audio block after it) goes to xo.
             if i < half:
-                src, dst = xn, xc
+                src = xn
             else:
-                L.gemm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], xc,
+                src = p["xS"]
+                L.gemm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src,
                        M=rows, N=D, compute=self.cdc, ldo=D)
-                src, dst = xc, xo
+            dst = xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
             L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
@@ -547,9 +553,23 @@ class DiTEngine:
                        epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
             self._norm_ada(x, p["hn_a"], rows, D, i, 2)
             self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2)))
-            eA = rec(main)
-            if i >= half:
-                xc, xo = xo, xc
+            if not last:
+                if not self.cross_on_main:
+                    eA = rec(main)             # x of the next layer is ready
+                # side streams: the NEXT layer's text / frames block beside this layer's audio block.  Issued AFTER the audio
+                # block in program order: a replayed hipGraph hands its kernels to the queues in capture order (a few us
+                # each), so whatever is captured first is submitted first -- with the side blocks in front, the audio
+                # stream (the critical path) sat idle for ~75 us per layer until 18 side kernels had been handed over.
+                with _On(st):
+                    wait(st, eX)
+                    self._side_block(nxt, "t", tbuf[0], tbuf[1], Bt, Dt)
+                    eT = rec(st)
+                with _On(sf):
+                    wait(sf, eX)
+                    self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df)
+                    eF = rec(sf)
+                tc_, fc_ = tbuf[1], fbuf[1]
+            xc, xo = xo, xc
         # final norm over all rows (registers are dropped by the consumer) + to_pred (x3:1141-1143, 2083)
         L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g)
         L.gemm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, compute=self.cdc, bias=W.pred_b,
