@@ -115,13 +115,13 @@ int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
 int v2a_gemm_args_size(void);
 
 /* Tile-selection overrides of v2a_gemm for A/B measurements (bench.py, scripts/).  Library defaults: force -1, rotation 0,
- * 8-phase kernel on (staggered) from 200 tiles.
+ * 8-phase kernel on (staggered) from 400 tiles.
  * Process-wide; call it between launches, not concurrently with them.  NULL restores the defaults. */
 typedef struct v2a_tuning {
   int32_t gemm_force_tile;        /* -1 = by shape; 0..5 = one LDS-DMA tile shape for every bf16 x bf16 GEMM, 6 = the 256x256 8-phase kernel */
   int32_t gemm_k_rotation;        /* 1: M bands that share a W panel start their K walk at different K tiles (changes fp32 summation order with M) */
   int32_t gemm_8phase;            /* 256x256 phase-interleaved kernel for wide outputs (N >= 2048): 0 off, 1 on (staggered wave rows), 2 on (lock-step) */
-  int32_t gemm_8phase_min_tiles;  /* ... when the problem yields at least this many 256x256 tiles (0 = 200) */
+  int32_t gemm_8phase_min_tiles;  /* ... when the problem yields at least this many 256x256 tiles (0 = 400) */
   int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass, 4 or 8 (0 = default) */
   int32_t reserved[3];
 } v2a_tuning;

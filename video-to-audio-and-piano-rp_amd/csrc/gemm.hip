@@ -385,9 +385,11 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-// defaults: phase-interleaved 256x256 kernel for wide outputs once a launch has >= 200 tiles (A/B on MI355X: +2.9 % at one clip,
-// +2.2 % at 8 clips per GPU end to end; with fewer tiles the 128x256 ring kernel fills the chip better)
-static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 200};
+// defaults: phase-interleaved 256x256 kernel for wide outputs once a launch has >= 400 tiles, i.e. from two clips per GPU on
+// (A/B on MI355X: +1..2 % at 8 clips per GPU end to end).  At one clip its 224-280 workgroups of 128 KB LDS take every CU for
+// 35-70 us: alone it is the fastest choice for the feed-forward GEMMs (774 vs 644 TF/s), beside the other two streams of the
+// sampler it costs 1.3 % end to end, and with fewer tiles the 128x256 ring kernel fills the chip better anyway.
+static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400};
 v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 
@@ -511,17 +513,37 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
       default: return dispatch_dma<64, 64, 2, 2>(a, p, s);
     }
   }
-  if (tune.force_tile == 6 || (tune.force_tile < 0 && tune.use_8phase && dense && a->N >= 2048 && ntiles(256, 256) >= tune.min_tiles_8phase))
-    return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
+  // Tile shape by how many workgroups the problem yields on 256 CUs (stand-alone launches measured with scripts/gemm_probe.py;
+  // M = 1564 / 3128 / 6256 / 12512 rows = 1 / 2 / 4 / 8 clips):
+  //   * 256x256 phase-interleaved kernel: wide outputs from min_tiles_8phase tiles; narrow outputs (512 < N < 2048) once they
+  //     fill >= 150 CUs with one tile each (8 clips: 1045 vs 793 TF/s at 12512x1024x4096, 1135 vs 967 at 12512x1280x5120);
+  //   * 128x256 ring kernel: wide outputs below that, narrow ones from ~4 clips (778 vs 534 TF/s at 6256x1024x4096) and
+  //     N <= 512 at 8 clips (653 vs 450 TF/s at 12512x512x2048);
+  //   * 128x128 from ~2 clips, 64x64 below (one clip: only small tiles give every CU work).
+  const bool can8 = tune.use_8phase && dense;
+  if (tune.force_tile == 6) return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
   int cfg;
   if (tune.force_tile >= 0) cfg = tune.force_tile;
   else if (a->N <= 64) cfg = ntiles(128, 64) >= 512 ? 2 : 3;          // conv layers with few output channels
   else if (a->N <= 128) cfg = ntiles(128, 128) >= 512 ? 1 : (ntiles(128, 64) >= 512 ? 2 : 3);
-  else if (ntiles(256, 256) >= 512 && a->N >= 2048) cfg = 5;          // batched clips, wide outputs: halve the fill bytes per flop
-  else if ((a->N >= 2048 && ntiles(128, 256) >= 96) || ntiles(128, 256) >= 200) cfg = 0;   // wide outputs, or large M
-  else if (ntiles(128, 128) >= 256) cfg = 1;                            // batched clips, narrow outputs
-  else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;
-  else cfg = 3;
+  else if (a->N >= 2048) {
+    if (can8 && ntiles(256, 256) >= tune.min_tiles_8phase) cfg = 6;
+    else if (ntiles(256, 256) >= 512) cfg = 5;                         // 8-phase kernel switched off: 2-deep ring of 64 KB stages
+    else if (ntiles(128, 256) >= 96) cfg = 0;
+    else cfg = 3;
+  } else if (a->N > 512) {
+    if (can8 && ntiles(256, 256) >= 150) cfg = 6;
+    else if (ntiles(128, 256) >= 180) cfg = 0;
+    else if (ntiles(128, 128) >= 180) cfg = 1;
+    else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;
+    else cfg = 3;
+  } else {
+    if (ntiles(128, 256) >= 150) cfg = 0;
+    else if (ntiles(128, 128) >= 256) cfg = 1;
+    else if (ntiles(64, 64) >= 2048 && ntiles(128, 64) >= 512) cfg = 2;
+    else cfg = 3;
+  }
+  if (cfg == 6) return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
   switch (cfg) {
     case 5: return dispatch_dma<256, 256, 2, 4, 2>(a, p, s); // 8 waves, 128x64 wave tiles, 2-deep ring of 64 KB stages
     case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);   // 8 waves, 144 KB LDS, 1 workgroup/CU

@@ -436,8 +436,10 @@ class DiTEngine:
         their own stream; the cross-condition reads the PRE-update x, text, frames; the audio block A_i needs
         the cross-conditioned x.  Hence T_{i+1} and F_{i+1} run beside A_i.  With side streams this is
         expressed by events (captured as hipGraph edges); without them everything is issued in order on
-        the current stream.  Two hand-offs per layer: side blocks done (eT, eF -> main's cross-condition GEMMs of the
-        next layer) and the three cross-condition GEMMs done (eX -> the side streams may start their next block)."""
+        the current stream.  Hand-offs per layer: side blocks done (eT, eF -> main's cross-condition GEMM of the next
+        layer), x of the layer ready (eA -> the side streams' own cross-condition GEMMs) and main's cross-condition GEMM
+        done (eX -> the side blocks may overwrite the text / frames buffers it read).  All are forward edges: the main
+        stream (the critical path) waits only for eT / eF, which the side streams reach with slack."""
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
         D, Dt, Df = c.dim, c.dim_text, c.dim_frames
@@ -505,13 +507,14 @@ class DiTEngine:
                     cross_f()
                     eX = rec(main)
                 else:
+                    # eX: main has read this layer's text / frames buffers (x_tfa) -- the side blocks below overwrite them
+                    eX = rec(main)
                     with _On(st):
                         wait(st, eA)
                         cross_t()
                     with _On(sf):
                         wait(sf, eA)
                         cross_f()
-                    eX = None
             # U-Net skip (x3:1108-1117).  First half: the cross-condition output buffer IS the saved skip.  Second half:
             # skip_proj(cat(x, skip)) -> spare buffer.  The conv output (and the whole audio block after it) goes to xo.
             if i < half:
