@@ -18,7 +18,8 @@ Rank 0 prints ONE JSON line.  At N = 1 it also carries
                  launched once, in its real cache state; interval = kernel + the launch boundary behind it), plus an
                  `hbm` block for the memory-bound kernels at 1 and 8 clips per GPU;
   parity_mode  : throughput AND max |delta mel| over the whole 32-point grid against the committed oracle vector
-                 (tests/golden/sample_full.npz) for the fp32 parity mode and the bf16 headline mode;
+                 (tests/golden/sample_full.npz) for the fp32 parity mode, the split-bf16 mode (bf16x3) and the bf16
+                 headline mode;
   v2p, cascade : BASELINE configs[3] / [4] as supplementary measurements;
   cpu_baseline : the CPU restatement of the reference (oracle/, "port") timed on this box's host
                  cores on a bounded sample of the same workload (steps=4: 3 CFG evaluations).
@@ -477,7 +478,7 @@ def parity_mode_leg(v2a_amd, cfg, args, dev):
     y0, text, roll, ctx, cm = O.synthetic_inputs(O.DiTConfig(), 1, 750, nc=16, seed=0)
     want, want_traj = torch.from_numpy(g["y_steps32"]), torch.from_numpy(g["traj32_sub"])
     out = {"fixture": "tests/golden/sample_full.npz (oracle, B=1, 32-point sway grid, CFG 2.0)", "tolerance_fp32": 1e-3}
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16x3", "bf16"):
         m = v2a_amd.E2TTS(transformer=dict(depth=cfg.depth, dim=cfg.dim, dim_text=cfg.dim_text, heads=cfg.heads, dim_head=cfg.dim_head,
                                            if_text_modules=True, if_cross_attn=True, if_audio_conv=True, if_text_conv=True),
                           num_channels=cfg.num_channels, sampling_rate=24000, if_cond_proj_in=False, compute_dtype=mode, device=dev)

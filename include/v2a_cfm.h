@@ -34,7 +34,16 @@ extern "C" {
 
 typedef void* v2a_stream_t; /* hipStream_t */
 
-enum { V2A_F32 = 0, V2A_BF16 = 1 };
+enum {
+  V2A_F32 = 0,
+  V2A_BF16 = 1,
+  /* split-bf16 operand layout (the "bf16x3" parity mode): a row of d fp32 values v is stored as 2*d bf16 values
+   * [hi_0 .. hi_{d-1} | lo_0 .. lo_{d-1}], hi = bf16(v), lo = bf16(v - hi).  A GEMM on the concatenation
+   * [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]^T (three K segments of v2a_gemm) then sums hi*hi + hi*lo + lo*hi in fp32:
+   * fp32-grade products (relative error ~2^-16) at three bf16 MFMAs instead of one fp32 MFMA at 1/16 of the rate.
+   * Accepted as y_dtype of v2a_rmsnorm and by v2a_split_bf16; never a compute dtype. */
+  V2A_BF16_SPLIT = 2
+};
 
 enum {
   V2A_OK = 0,
@@ -78,7 +87,7 @@ typedef struct v2a_gemm_args {
   int32_t epilogue;      /* V2A_EPI_*                                                   */
   void* out;             /* [M][N] (GEGLU: [M][N/2])                                    */
   int64_t ldo;
-  int32_t out_dtype;     /* V2A_F32 | V2A_BF16 (RESID/GATE_RESID/SIGMOID: f32 only)     */
+  int32_t out_dtype;     /* V2A_F32 | V2A_BF16 (RESID/GATE_RESID/SIGMOID: f32 only; GEGLU: bf16, or f32 with bf16 compute) */
   void* out_bf16;        /* optional bf16 shadow copy of an f32 output (operand of a later GEMM), or NULL */
   int64_t ld_out_bf16;
   const float* resid;    /* [M][ldr] f32; may alias out                                 */
@@ -130,7 +139,8 @@ int v2a_set_tuning(const v2a_tuning* tuning);
 /* ---------------------------------------------------------------------------------------
  * RMSNorm / AdaptiveRMSNorm:  y = x / max(|x|_2, 1e-12) * sqrt(d) * gamma
  * gamma is a step vector: RMSNorm passes g (strides 0); AdaptiveRMSNorm passes the
- * precomputed (to_gamma(c) + 1) table.  Output in the compute dtype (GEMM operand).
+ * precomputed (to_gamma(c) + 1) table.  Output in the compute dtype (GEMM operand); y_dtype V2A_BF16_SPLIT writes the
+ * hi / lo planes of the split layout (ldy >= 2*d).
  * Replaces: xt RMSNorm (x3:880,883,913,916,935), xt AdaptiveRMSNorm (x3:807,812,816).
  * ------------------------------------------------------------------------------------- */
 int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t y_dtype,
@@ -228,6 +238,10 @@ int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C,
                   int64_t pred_batch_stride, int32_t row_off, float cfg_strength,
                   const float* dt, const int32_t* step, const double* apg,
                   float keep_parallel_frac, v2a_stream_t stream);
+/* y[r][0:d] = hi, y[r][d:2d] = lo of x[r][0:d] (V2A_BF16_SPLIT layout above), rows x d fp32 in, row strides in elements,
+ * d % 4 == 0: the split operand copy of an fp32 buffer (residual streams, attention outputs, GEGLU hidden) for the
+ * three-segment bf16 GEMMs of the bf16x3 mode */
+int v2a_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t d, v2a_stream_t stream);
 /* y[i] = bf16(x[i]), n % 4 == 0: bf16 operand copy of an fp32 stream that no GEMM epilogue produced
  * (the embed output x3:2027 feeding the first cross-condition GEMM) */
 int v2a_cast_bf16(const float* x, void* y, int64_t n, v2a_stream_t stream);

@@ -110,6 +110,19 @@ def test_full_sample_steps32_fp32_every_grid_point(full, m32):
     assert float(per_point.max()) < 1e-3 and err < 1e-3
 
 
+def test_full_sample_steps32_split_bf16_every_grid_point(full):
+    """configs[1] in the bf16x3 mode (split-bf16 GEMMs on the bf16 MFMA path): the same 1e-3 gate over the whole grid."""
+    f = full
+    m = make_model(f["cfg"], f["P"], "bf16x3")
+    traj = []
+    got = _sample(m, f, 32, trajectory_out=traj)
+    sub = torch.stack([t[0, ::8].cpu() for t in traj])
+    per_point = (sub - f["g"]["traj32_sub"]).abs().amax(dim=(1, 2))
+    err = float((got[0] - f["g"]["y_steps32"]).abs().max())
+    print("full-shape bf16x3 32-step sample: final max |delta mel| = %.3e; per grid point max %.3e" % (err, float(per_point.max())))
+    assert float(per_point.max()) < 1e-3 and err < 1e-3
+
+
 def test_full_sample_steps32_bf16_report(full, mbf):
     """The benchmarked mode on the same grid: drift over 31 evaluations, reported (bf16 operands are narrower than the
     reference's fp32 arithmetic: this mode carries no 1e-3 claim)."""

@@ -568,3 +568,41 @@ def test_cross_condition_vs_reference_module(L, intree, flag):
         L.gemm([(ad, da, da), (fd, df, df)], r["cc_1_audio_to_frames_weight"].to(DEV), of, M=M, N=df, compute=L.F32, epilogue=L.EPI_RESID, resid=fd)
         torch.testing.assert_close(ot.cpu().reshape(Bt, N, dt), r["cc_1_out_text"], atol=2e-5, rtol=1e-5)
         torch.testing.assert_close(of.cpu().reshape(Bt, N, df), r["cc_1_out_frames"], atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------ split-bf16 ("bf16x3") building blocks
+def test_split_bf16_planes_and_three_segment_gemm(L):
+    """v2a_split_bf16 / rmsnorm(split) write hi | lo planes; the three-segment GEMM [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]^T
+    reproduces the fp32 product to ~1e-5 relative (bf16 alone: ~1e-2)."""
+    from v2a_amd.dit import pack_weight
+    M, K, N = 300, 256, 192
+    g = _g(11)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    ad = a.to(DEV)
+    sp = torch.empty(M, 2 * K, dtype=torch.bfloat16, device=DEV)
+    L.split_bf16(ad, sp, rows=M, d=K)
+    hi, lo = sp[:, :K].float().cpu(), sp[:, K:].float().cpu()
+    assert torch.equal(hi, a.bfloat16().float()) and torch.equal(lo, (a - a.bfloat16().float()).bfloat16().float())
+    assert float((hi + lo - a).abs().max()) < 2e-5 * float(a.abs().max())
+    W3 = pack_weight(w, DEV, torch.bfloat16, split=True)
+    assert len(W3) == 1 and W3[0].shape == (N, 3 * K)
+    out = torch.empty(M, N, device=DEV)
+    L.gemm([(sp, 2 * K, K), (sp, 2 * K, K), (sp[:, K:], 2 * K, K)], W3[0], out, M=M, N=N, compute=L.BF16)
+    ref = a.double() @ w.double().t()
+    err3 = float((out.cpu().double() - ref).abs().max())
+    out1 = torch.empty(M, N, device=DEV)
+    L.gemm([(a.bfloat16().to(DEV), K, K)], w.bfloat16().to(DEV), out1, M=M, N=N, compute=L.BF16)
+    err1 = float((out1.cpu().double() - ref).abs().max())
+    print(f"split-bf16 GEMM max err {err3:.2e} (plain bf16 {err1:.2e})")
+    assert err3 < 3e-5 and err3 < err1 / 100
+    # rmsnorm with split output == split of the fp32 rmsnorm
+    gam = 1 + 0.1 * torch.randn(K, generator=g)
+    y32 = torch.empty(M, K, device=DEV)
+    L.rmsnorm(ad, y32, rows=M, d=K, gamma=gam.to(DEV))
+    ys = torch.empty(M, 2 * K, dtype=torch.bfloat16, device=DEV)
+    L.rmsnorm(ad, ys, rows=M, d=K, gamma=gam.to(DEV), split=True)
+    L.split_bf16(y32, sp, rows=M, d=K)
+    assert torch.equal(ys[:, :K].cpu(), sp[:, :K].cpu())                      # hi planes identical
+    rec = ys[:, :K].float() + ys[:, K:].float()                              # lo may use a fused multiply-subtract: compare the sum
+    assert float((rec - y32).abs().max()) < 2e-5 * float(y32.abs().max())

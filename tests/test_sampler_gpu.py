@@ -76,6 +76,27 @@ def test_sample_vs_golden(small, golden, model_fp32, case):
         assert np.abs(y.numpy() - ref).max() < TOL, np.abs(y.numpy() - ref).max()
 
 
+@pytest.mark.parametrize("case", ["y_full", "y_ragged", "y_apg"])
+def test_sample_vs_golden_split_bf16(small, golden, case):
+    """compute_dtype="bf16x3": GEMM operands as bf16 hi | lo planes (three bf16 MFMA products per fp32 product), everything
+    else as in fp32 mode -- must meet the same 1e-3 gate as the exact-fp32 path."""
+    from conftest import make_model
+    i, g = small["inp"], golden["sample_small"]
+    m = make_model(small["cfg"], small["P"], "bf16x3")
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False, return_raw_output=True)
+    if case == "y_ragged":
+        kw.update(lens=torch.tensor([40, 29]), duration=torch.tensor([40, 29]))
+    if case == "y_apg":
+        kw.update(remove_parallel_component=True)
+    y = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+    ref = g[case]
+    err = np.abs(y.numpy()[0] - ref[0]).max() if case == "y_ragged" else np.abs(y.numpy() - ref).max()
+    if case == "y_ragged":
+        err = max(err, np.abs(y.numpy()[1, :29] - ref[1, :29]).max())
+    print(f"bf16x3 small {case}: max |delta mel| = {err:.3e}")
+    assert err < TOL
+
+
 def test_sample_half_layout_and_no_cross_rope(small, golden):
     i, g = small["inp"], golden["sample_small"]
     kw = dict(steps=4, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("V2A_CFM_LIB") or os.path.join(_HERE, "libv2a_cfm.so")   # V2A_CFM_LIB: A/B tuning aid
 CSRC = os.path.join(_HERE, "csrc")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16_SPLIT = 0, 1, 2
 EPI_STORE, EPI_SIGMOID, EPI_GEGLU, EPI_RESID, EPI_GATE_RESID = 0, 1, 2, 3, 4
 
 _lib = None
@@ -73,7 +73,7 @@ class RollHeadArgs(C.Structure):
 EXPORTS = [
     "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
-    "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16",
+    "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16", "v2a_split_bf16",
     "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
     "v2a_elu_pad", "v2a_lstm_layer", "v2a_lstm2",
 ]
@@ -111,6 +111,7 @@ def _declare(lib):
     lib.v2a_cfg_euler.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, f32, vp]
     lib.v2a_step_advance.argtypes = [vp, vp]
     lib.v2a_cast_bf16.argtypes = [vp, vp, i64, vp]
+    lib.v2a_split_bf16.argtypes = [vp, i64, vp, i64, i64, i32, vp]
     lib.v2a_im2col.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, i32, i32, vp]
     lib.v2a_frames_pack.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.v2a_pool2d.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -301,9 +302,14 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
 
 
 def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch_stride=0, rows_per_batch=0,
-            ldx=None, ldy=None):
-    _launch("rmsnorm<%s>" % ("f32" if y.dtype == torch.float32 else "bf16"), 0.0, rows * d * (4 + y.element_size()),
-            lambda: lib().v2a_rmsnorm(x.data_ptr(), ldx or d, y.data_ptr(), ldy or d, dt_code(y.dtype), rows, d,
+            ldx=None, ldy=None, split=False):
+    """split=True: y is a (rows, 2*d) bf16 buffer that receives the hi | lo planes (BF16_SPLIT)."""
+    ydt = BF16_SPLIT if split else dt_code(y.dtype)
+    if split:
+        ldy = ldy or 2 * d
+    _launch("rmsnorm<%s>" % ("f32" if y.dtype == torch.float32 else ("bf16x2" if split else "bf16")), 0.0,
+            rows * d * (4 + y.element_size() * (2 if split else 1)),
+            lambda: lib().v2a_rmsnorm(x.data_ptr(), ldx or d, y.data_ptr(), ldy or d, ydt, rows, d,
                                       gamma.data_ptr(), _p(step), gamma_step_stride, gamma_batch_stride, rows_per_batch,
                                       stream_ptr()))
 
@@ -361,6 +367,11 @@ def cfg_euler(y, pred, *, B, T, C_, pred_batch_stride, row_off, cfg_strength, dt
 
 def step_advance(step):
     check(lib().v2a_step_advance(step.data_ptr(), stream_ptr()))
+
+
+def split_bf16(x, y, *, rows, d, ldx=None, ldy=None):
+    """fp32 (rows, d) -> bf16 (rows, 2*d) hi | lo planes."""
+    _launch("split_bf16", 0.0, rows * d * 8, lambda: lib().v2a_split_bf16(x.data_ptr(), ldx or d, y.data_ptr(), ldy or 2 * d, rows, d, stream_ptr()))
 
 
 def cast_bf16(x, y):

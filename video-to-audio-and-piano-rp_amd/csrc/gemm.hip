@@ -370,9 +370,8 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
   switch (a->epilogue) {
     case V2A_EPI_STORE:
       return out_f32 ? launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST>(p, s) : launch_dma<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
-    case V2A_EPI_GEGLU:
-      if (!out_f32) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
-      break;
+    case V2A_EPI_GEGLU:   // fp32 output: the hidden activation of the bf16x3 mode, split into hi / lo planes afterwards
+      return out_f32 ? launch_dma<V2A_EPI_GEGLU, float, BM, BN, WGM, WGN, NST>(p, s) : launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
     case V2A_EPI_RESID:
       if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN, NST>(p, s);
       break;

@@ -247,8 +247,7 @@ int v2a_detail::launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dt
     case V2A_EPI_STORE:
       return out_f32 ? launch_8ph<V2A_EPI_STORE, float>(p, s) : launch_8ph<V2A_EPI_STORE, bf16_t>(p, s);
     case V2A_EPI_GEGLU:
-      if (!out_f32) return launch_8ph<V2A_EPI_GEGLU, bf16_t>(p, s);
-      break;
+      return out_f32 ? launch_8ph<V2A_EPI_GEGLU, float>(p, s) : launch_8ph<V2A_EPI_GEGLU, bf16_t>(p, s);
     case V2A_EPI_RESID:
       if (out_f32) return launch_8ph<V2A_EPI_RESID, float>(p, s);
       break;

@@ -17,7 +17,7 @@ namespace {
 // RMSNorm: one wave per row; the row (d <= 2048 floats) stays in registers between the
 // sum-of-squares pass and the scale pass, so x is read once: 4*d B in, sizeof(T)*d B out.
 // ------------------------------------------------------------------------------------------
-template <typename OutT, int VPL /* float4 per lane */>
+template <typename OutT, int VPL /* float4 per lane */, bool SPLIT = false /* bf16 hi | lo planes, lo at + d */>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int64_t ldx, OutT* __restrict__ y,
                                                       int64_t ldy, int64_t rows, int d, const float* gamma,
                                                       const int32_t* step, int64_t gss, int64_t gbs, int rpb) {
@@ -56,6 +56,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[i][j] * inv * gv[j]);
         *reinterpret_cast<bf16x4*>(yr + 4 * c) = o;
+        if constexpr (SPLIT) {
+          bf16x4 lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lo[j] = (bf16_t)(v[i][j] * inv * gv[j] - (float)o[j]);
+          *reinterpret_cast<bf16x4*>(yr + d + 4 * c) = lo;
+        }
       }
     }
   }
@@ -397,6 +403,25 @@ __global__ __launch_bounds__(256) void apg_reduce_kernel(const float* __restrict
 
 __global__ void step_advance_kernel(int32_t* step) { step[0] += 1; }
 
+// rows x d fp32 -> bf16 hi | lo planes (V2A_BF16_SPLIT); one thread per float4
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t ldy,
+                                                         int64_t rows, int d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = d >> 2;
+  if (i >= rows * per) return;
+  const int64_t r = i / per;
+  const int c = (int)(i % per) * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+  bf16x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (bf16_t)v[j];
+    lo[j] = (bf16_t)(v[j] - (float)hi[j]);
+  }
+  *reinterpret_cast<bf16x4*>(y + r * ldy + c) = hi;
+  *reinterpret_cast<bf16x4*>(y + r * ldy + d + c) = lo;
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
@@ -416,7 +441,8 @@ extern "C" int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, in
   V2A_REQUIRE(x && y && gamma, "v2a_rmsnorm: null pointer");
   V2A_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 2048, "v2a_rmsnorm: d=%d (need d %% 4 == 0, d <= 2048)", d);
   V2A_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && gss % 4 == 0 && gbs % 4 == 0, "v2a_rmsnorm: strides must be multiples of 4");
-  V2A_REQUIRE(y_dtype == V2A_F32 || y_dtype == V2A_BF16, "v2a_rmsnorm: y dtype %d", y_dtype);
+  V2A_REQUIRE(y_dtype == V2A_F32 || y_dtype == V2A_BF16 || y_dtype == V2A_BF16_SPLIT, "v2a_rmsnorm: y dtype %d", y_dtype);
+  V2A_REQUIRE(y_dtype != V2A_BF16_SPLIT || ldy >= 2 * (int64_t)d, "v2a_rmsnorm: split output needs ldy >= 2*d");
   if (rpb <= 0) rpb = (int32_t)rows;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
@@ -425,7 +451,12 @@ extern "C" int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, in
   hipLaunchKernelGGL((rmsnorm_kernel<OT, V>), grid, block, 0, s, x, ldx, (OT*)y, ldy, rows, d, gamma, step, gss, gbs, rpb)
   // exact float4-per-lane counts for the widths of the path (512 -> 2, 1024 -> 4, 1280 -> 5): with the 8-wide instantiation
   // d = 1280 carried three dead, bounds-checked vectors per lane and streamed 2.9 TB/s against 5.1 TB/s at d = 1024
-  if (y_dtype == V2A_F32) {
+  if (y_dtype == V2A_BF16_SPLIT) {
+#define V2A_RMS_S(V) hipLaunchKernelGGL((rmsnorm_kernel<bf16_t, V, true>), grid, block, 0, s, x, ldx, (bf16_t*)y, ldy, rows, d, gamma, step, gss, gbs, rpb)
+    if (vpl <= 1) V2A_RMS_S(1); else if (vpl <= 2) V2A_RMS_S(2); else if (vpl <= 3) V2A_RMS_S(3); else if (vpl <= 4) V2A_RMS_S(4);
+    else if (vpl <= 5) V2A_RMS_S(5); else if (vpl <= 6) V2A_RMS_S(6); else V2A_RMS_S(8);
+#undef V2A_RMS_S
+  } else if (y_dtype == V2A_F32) {
     if (vpl <= 1) V2A_RMS(float, 1); else if (vpl <= 2) V2A_RMS(float, 2); else if (vpl <= 3) V2A_RMS(float, 3); else if (vpl <= 4) V2A_RMS(float, 4);
     else if (vpl <= 5) V2A_RMS(float, 5); else if (vpl <= 6) V2A_RMS(float, 6); else V2A_RMS(float, 8);
   } else {
@@ -531,6 +562,15 @@ extern "C" int v2a_step_advance(int32_t* step, v2a_stream_t stream) {
   V2A_REQUIRE(step, "v2a_step_advance: null pointer");
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
   return v2a_check_launch("v2a_step_advance");
+}
+
+extern "C" int v2a_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t d, v2a_stream_t stream) {
+  V2A_REQUIRE(x && y && rows > 0 && d > 0 && d % 4 == 0, "v2a_split_bf16: bad args (d %% 4 must be 0)");
+  V2A_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldy >= 2 * (int64_t)d && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0,
+              "v2a_split_bf16: strides / alignment (ldy >= 2*d)");
+  const int64_t n4 = rows * (d / 4);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16_t*)y, ldy, rows, d);
+  return v2a_check_launch("v2a_split_bf16");
 }
 
 extern "C" int v2a_cast_bf16(const float* x, void* y, int64_t n, v2a_stream_t stream) {

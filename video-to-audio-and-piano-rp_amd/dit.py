@@ -63,10 +63,29 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+def pack_weight(w, dev, cd, split=False, ksegs=None):
+    """nn.Linear weight [N][K] -> device operand.  Plain modes: one tensor in the compute dtype.  split (bf16x3 mode): one
+    tensor PER K segment (ksegs: the K extents of the concatenated inputs, default one segment), each [N][3*Ks] bf16 =
+    [W_hi | W_lo | W_hi] with W_hi = bf16(W), W_lo = bf16(W - W_hi): against the operand [A_hi | A_hi | A_lo] a three-segment
+    bf16 GEMM then sums hi*hi + hi*lo + lo*hi in fp32 (include/v2a_cfm.h, V2A_BF16_SPLIT)."""
+    w = w.float()
+    if not split:
+        return w.to(dev, cd).contiguous()
+    out, k0 = [], 0
+    for k in (ksegs or [w.shape[1]]):
+        ws = w[:, k0:k0 + k]
+        hi = ws.bfloat16()
+        lo = (ws - hi.float()).bfloat16()
+        out.append(torch.cat([hi, lo, hi], 1).contiguous().to(dev))
+        k0 += k
+    assert k0 == w.shape[1]
+    return out
+
+
 class _Attn:
     """Packed weights of one x-transformers Attention (A1, A5 of SURVEY 8c)."""
 
-    def __init__(self, sd, prefix, dim, heads, dh, cd, dev, cross=False):
+    def __init__(self, sd, prefix, dim, heads, dh, cd, dev, cross=False, split=False):
         inner = heads * dh
         wq, wk, wv = sd[f"{prefix}.to_q.weight"], sd[f"{prefix}.to_k.weight"], sd[f"{prefix}.to_v.weight"]
         wg, bg = sd[f"{prefix}.to_v_head_gate.weight"], sd[f"{prefix}.to_v_head_gate.bias"]
@@ -79,25 +98,25 @@ class _Attn:
         b = torch.zeros(self.n_pad, dtype=torch.float32)
         self.gate_col = n - heads
         b[self.gate_col:n] = bg.float()
-        self.w_in = w.to(dev, cd).contiguous()      # [q|k|v|gate] or [q|gate] rows
+        self.w_in = pack_weight(w, dev, cd, split)      # [q|k|v|gate] or [q|gate] rows
         self.b_in = b.to(dev)
-        self.w_out = sd[f"{prefix}.to_out.weight"].to(dev, cd).contiguous()
+        self.w_out = pack_weight(sd[f"{prefix}.to_out.weight"], dev, cd, split)
         self.wk, self.wv = (wk, wv) if cross else (None, None)
 
 
 class _FF:
     """Packed GEGLU feed-forward (A8): W1 rows regrouped [16 value | 16 gate] per 16 outputs."""
 
-    def __init__(self, sd, prefix, dim, cd, dev):
+    def __init__(self, sd, prefix, dim, cd, dev, split=False):
         w1, b1 = sd[f"{prefix}.ff.0.proj.weight"].float(), sd[f"{prefix}.ff.0.proj.bias"].float()
         inner = w1.shape[0] // 2
         assert inner % 16 == 0
         self.inner = inner
         wv, wg = w1[:inner].reshape(inner // 16, 1, 16, dim), w1[inner:].reshape(inner // 16, 1, 16, dim)
-        self.w1 = torch.cat([wv, wg], 1).reshape(2 * inner, dim).to(dev, cd).contiguous()
+        self.w1 = pack_weight(torch.cat([wv, wg], 1).reshape(2 * inner, dim), dev, cd, split)
         bv, bgt = b1[:inner].reshape(inner // 16, 1, 16), b1[inner:].reshape(inner // 16, 1, 16)
         self.b1 = torch.cat([bv, bgt], 1).reshape(2 * inner).to(dev).contiguous()
-        self.w2 = sd[f"{prefix}.ff.2.weight"].to(dev, cd).contiguous()
+        self.w2 = pack_weight(sd[f"{prefix}.ff.2.weight"], dev, cd, split)
         self.b2 = sd[f"{prefix}.ff.2.bias"].float().to(dev).contiguous()
 
 
@@ -112,8 +131,9 @@ class _Conv:
 class PackedWeights:
     """Reference state_dict (key layout of x3:824-933) -> device blobs."""
 
-    def __init__(self, cfg: DiTConfig, sd: dict, dev, cd: torch.dtype):
+    def __init__(self, cfg: DiTConfig, sd: dict, dev, cd: torch.dtype, split: bool = False):
         c = cfg
+        pk = lambda w, ksegs=None: pack_weight(w, dev, cd, split, ksegs)
         T = "transformer"
         f32 = lambda k: sd[k].float().to(dev).contiguous()
         self.pos_emb = f32(f"{T}.abs_pos_emb.weight")
@@ -128,7 +148,7 @@ class PackedWeights:
         self.pin_b = f32("proj_in.bias")
         self.pf_wt = sd["proj_frames.weight"].float().t().contiguous().to(dev)               # [51][df]
         self.pf_b = f32("proj_frames.bias")
-        self.pred_w = sd["to_pred.weight"].to(dev, cd).contiguous()
+        self.pred_w = pk(sd["to_pred.weight"])
         self.pred_b = f32("to_pred.bias")
         self.layers = []
         ng, gw, gb, kw, vw = [], [], [], [], []
@@ -136,11 +156,11 @@ class PackedWeights:
             P = f"{T}.layers.{i}"
             ly = {}
             if i >= c.depth // 2:
-                ly["skip"] = sd[f"{P}.0.0.weight"].to(dev, cd).contiguous()
+                ly["skip"] = pk(sd[f"{P}.0.0.weight"], [c.dim, c.dim])
             ly["a_conv"] = _Conv(sd, f"{P}.0.1", dev)
-            ly["a_attn"] = _Attn(sd, f"{P}.0.3", c.dim, c.heads, c.dim_head, cd, dev)
-            ly["a_attn2"] = _Attn(sd, f"{P}.0.6", c.dim, c.heads, c.dim_head, cd, dev, cross=True)
-            ly["a_ff"] = _FF(sd, f"{P}.0.9", c.dim, cd, dev)
+            ly["a_attn"] = _Attn(sd, f"{P}.0.3", c.dim, c.heads, c.dim_head, cd, dev, split=split)
+            ly["a_attn2"] = _Attn(sd, f"{P}.0.6", c.dim, c.heads, c.dim_head, cd, dev, cross=True, split=split)
+            ly["a_ff"] = _FF(sd, f"{P}.0.9", c.dim, cd, dev, split)
             ng += [sd[f"{P}.0.2.to_gamma.weight"], sd[f"{P}.0.5.to_gamma.weight"], sd[f"{P}.0.8.to_gamma.weight"]]
             gw += [sd[f"{P}.0.4.to_gamma.weight"], sd[f"{P}.0.7.to_gamma.weight"], sd[f"{P}.0.10.to_gamma.weight"]]
             gb += [sd[f"{P}.0.4.to_gamma.bias"], sd[f"{P}.0.7.to_gamma.bias"], sd[f"{P}.0.10.to_gamma.bias"]]
@@ -148,18 +168,18 @@ class PackedWeights:
             vw.append(ly["a_attn2"].wv)
             ly["t_conv"] = _Conv(sd, f"{P}.1.0", dev)
             ly["t_g1"] = f32(f"{P}.1.1.g")
-            ly["t_attn"] = _Attn(sd, f"{P}.1.2", c.dim_text, c.heads, c.dim_head, cd, dev)
+            ly["t_attn"] = _Attn(sd, f"{P}.1.2", c.dim_text, c.heads, c.dim_head, cd, dev, split=split)
             ly["t_g2"] = f32(f"{P}.1.3.g")
-            ly["t_ff"] = _FF(sd, f"{P}.1.4", c.dim_text, cd, dev)
-            ly["x_tfa"] = sd[f"{P}.1.5.text_frames_to_audio.weight"].to(dev, cd).contiguous()
+            ly["t_ff"] = _FF(sd, f"{P}.1.4", c.dim_text, cd, dev, split)
+            ly["x_tfa"] = pk(sd[f"{P}.1.5.text_frames_to_audio.weight"], [c.dim, c.dim_text, c.dim_frames])
             if i != c.depth - 1:
-                ly["x_at"] = sd[f"{P}.1.5.audio_to_text.weight"].to(dev, cd).contiguous()
-                ly["x_af"] = sd[f"{P}.1.5.audio_to_frames.weight"].to(dev, cd).contiguous()
+                ly["x_at"] = pk(sd[f"{P}.1.5.audio_to_text.weight"], [c.dim, c.dim_text])
+                ly["x_af"] = pk(sd[f"{P}.1.5.audio_to_frames.weight"], [c.dim, c.dim_frames])
             ly["f_conv"] = _Conv(sd, f"{P}.2.0", dev)
             ly["f_g1"] = f32(f"{P}.2.1.g")
-            ly["f_attn"] = _Attn(sd, f"{P}.2.2", c.dim_frames, c.frames_heads, c.dim_head, cd, dev)
+            ly["f_attn"] = _Attn(sd, f"{P}.2.2", c.dim_frames, c.frames_heads, c.dim_head, cd, dev, split=split)
             ly["f_g2"] = f32(f"{P}.2.3.g")
-            ly["f_ff"] = _FF(sd, f"{P}.2.4", c.dim_frames, cd, dev)
+            ly["f_ff"] = _FF(sd, f"{P}.2.4", c.dim_frames, cd, dev, split)
             self.layers.append(ly)
         # modulation tables: rows ordered (layer, slot) with slot = attn / cross-attn / ff
         self.norm_gamma_w = torch.cat([w.float() for w in ng], 0).to(dev).contiguous()       # (L*3*d, d) fp32
@@ -167,7 +187,7 @@ class PackedWeights:
         self.gate_w = torch.cat([w.float() for w in gw], 0).to(dev).contiguous()
         self.gate_b = torch.cat([b.float() for b in gb], 0).to(dev).contiguous()
         # cross-attention K/V projections of every layer stacked: [K_0..K_{L-1} | V_0..V_{L-1}]
-        self.ctx_kv_w = torch.cat([w.float() for w in kw] + [w.float() for w in vw], 0).to(dev, cd).contiguous()
+        self.ctx_kv_w = pk(torch.cat([w.float() for w in kw] + [w.float() for w in vw], 0))
         for ly in self.layers:
             ly["a_attn2"].wk = ly["a_attn2"].wv = None
 
@@ -196,7 +216,10 @@ class DiTEngine:
     def __init__(self, cfg: DiTConfig, state_dict: dict, device="cuda", compute: str = "bf16",
                  rope_layout: str = "interleaved", rope_cross: bool = True,
                  zero_masked_queries: bool = True, softclamp: float = 50.0, multi_stream: bool = True):
-        assert compute in ("bf16", "fp32")
+        assert compute in ("bf16", "fp32", "bf16x3")
+        # "bf16x3": GEMM operands as bf16 hi | lo planes, three bf16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi);
+        # attention, norms, conv, residual streams in fp32 as in parity mode -- fp32-grade results at a third of bf16 speed
+        self.split = compute == "bf16x3"
         self.multi_stream = multi_stream
         # GEMMs of the text / frames blocks: tile configuration 0 (128x256, one 144 KB workgroup per CU) when they run beside the
         # audio block on side streams -- few fat workgroups that own whole CUs disturb the critical path less than many small
@@ -205,18 +228,20 @@ class DiTEngine:
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # RoPE rides in the QKV GEMM epilogue when pairs are lane-local (interleaved layout, bf16 DMA kernel)
-        self._fuse_rope = compute == "bf16" and rope_layout == "interleaved"
+        self._fuse_rope = compute != "fp32" and rope_layout == "interleaved"
         assert cfg.dim_head == 64, "kernels are built for dim_head = 64 (x3:717)"
         self.cfg = cfg
         self.dev = torch.device(device)
-        self.cd = torch.bfloat16 if compute == "bf16" else torch.float32
-        self.cdc = L.BF16 if compute == "bf16" else L.F32
+        self.cd = torch.float32 if compute == "fp32" else torch.bfloat16      # dtype of GEMM operand buffers
+        self.cdc = L.F32 if compute == "fp32" else L.BF16                      # compute dtype of the GEMMs
+        self.ad = torch.bfloat16 if compute == "bf16" else torch.float32      # dtype of q | k | v | gate and attention outputs
+        self.adc = L.BF16 if compute == "bf16" else L.F32
         self.rope_layout = {"interleaved": 0, "half": 1}[rope_layout]
         self.rope_cross = rope_cross
         self.zero_masked_queries = zero_masked_queries
         self.softclamp = float(softclamp)
         L.lib()  # fail loudly now if the HIP library is absent
-        self.W = PackedWeights(cfg, state_dict, self.dev, self.cd)
+        self.W = PackedWeights(cfg, state_dict, self.dev, self.cd, self.split)
         self.plan = None
 
     # ------------------------------------------------------------------------------ planning
@@ -238,24 +263,29 @@ class DiTEngine:
         p["tA"], p["tB"], p["t0"], p["tL0"] = e(Bt, N, Dt), e(Bt, N, Dt), e(Bt, N, Dt), e(Bt, N, Dt)
         p["fA"], p["fB"], p["f0"], p["fL0"] = e(Bt, N, Df), e(Bt, N, Df), e(Bt, N, Df), e(Bt, N, Df)
         W0 = self.W.layers[0]
+        w2 = 2 if self.split else 1           # split operand buffers hold hi | lo planes
         for s, d, attn, ff in (("a", D, W0["a_attn"], W0["a_ff"]), ("t", Dt, W0["t_attn"], W0["t_ff"]),
                                ("f", Df, W0["f_attn"], W0["f_ff"])):
-            p[f"hn_{s}"] = e(rows, d, dt=cd)
-            p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=cd)
-            p[f"ao_{s}"] = e(rows, attn.inner, dt=cd)
-            p[f"ffh_{s}"] = e(rows, ff.inner, dt=cd)
+            p[f"hn_{s}"] = e(rows, w2 * d, dt=cd)
+            p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=self.ad)
+            p[f"ao_{s}"] = e(rows, w2 * attn.inner, dt=cd)
+            p[f"ffh_{s}"] = e(rows, w2 * ff.inner, dt=cd)
+            if self.split:                    # fp32 results that are split into operand planes afterwards
+                p[f"ao32_{s}"] = e(rows, attn.inner)
+                p[f"ffh32_{s}"] = e(rows, ff.inner)
         # bf16 shadows of the fp32 residual streams (written by the producing GEMM epilogues): the
         # operands of the cross-condition / skip GEMMs, so those run on the LDS-DMA bf16 kernel too
         p["shadow"] = {}
         if cd == torch.bfloat16:
+            mk = lambda t: torch.empty(*t.shape[:-1], w2 * t.shape[-1], dtype=cd, device=dev)
             for name in ("xA", "xB", "tA", "tB", "tL0", "fA", "fB", "fL0"):
-                p["shadow"][p[name].data_ptr()] = torch.empty_like(p[name], dtype=cd)
+                p["shadow"][p[name].data_ptr()] = mk(p[name])
             for sk in p["skips"]:
-                p["shadow"][sk.data_ptr()] = torch.empty_like(sk, dtype=cd)
-        p["q2"] = e(B * N, W0["a_attn2"].n_pad, dt=cd)
+                p["shadow"][sk.data_ptr()] = mk(sk)
+        p["q2"] = e(B * N, W0["a_attn2"].n_pad, dt=self.ad)
         inner = c.heads * c.dim_head
-        p["ctx_kv"] = e(B * nc, 2 * c.depth * inner, dt=cd)
-        p["ctx"] = e(B * nc, c.ctx_dim, dt=cd)
+        p["ctx_kv"] = e(B * nc, 2 * c.depth * inner, dt=self.ad)
+        p["ctx"] = e(B * nc, w2 * c.ctx_dim, dt=cd)
         p["ctx_len"] = torch.full((B,), nc, dtype=torch.int32, device=dev)
         p["pred"] = e(Bt, N, c.num_channels)
         p["tc"] = e(S, D)
@@ -288,17 +318,36 @@ class DiTEngine:
         s = self._sh(buf)
         return buf if s is None else s
 
+    def _mm(self, segs, W, out, **kw):
+        """GEMM on logical K segments [(operand buffer, lda, k)].  Plain modes: one v2a_gemm.  bf16x3: every logical segment
+        is its own launch on the three physical segments [A_hi | A_hi | A_lo] against [W_hi | W_lo | W_hi] (pack_weight);
+        launches after the first accumulate in place (RESID with resid = out), a requested bf16 shadow of the result is
+        produced by v2a_split_bf16 afterwards."""
+        if not self.split:
+            return L.gemm(segs, W, out, compute=self.cdc, **kw)
+        shadow = kw.pop("out_bf16", None)
+        for si, (buf, _, k) in enumerate(segs):
+            b2 = buf.reshape(-1, 2 * k)
+            kwi = dict(kw)
+            if si > 0:
+                kwi.update(bias=None, resid=out, ldr=kw.get("ldo"))
+                if kwi.get("epilogue", L.EPI_STORE) == L.EPI_STORE:
+                    kwi["epilogue"] = L.EPI_RESID
+            L.gemm([(b2, 2 * k, k), (b2, 2 * k, k), (b2[:, k:], 2 * k, k)], W[si], out, compute=L.BF16, **kwi)
+        if shadow is not None:
+            L.split_bf16(out, shadow, rows=kw["M"], d=kw["N"], ldx=kw.get("ldo"))
+
     def _norm_plain(self, x, hn, rows, d, g):
-        L.rmsnorm(x, hn, rows=rows, d=d, gamma=g)
+        L.rmsnorm(x, hn, rows=rows, d=d, gamma=g, split=self.split)
 
     def _norm_ada(self, x, hn, rows, d, layer, slot):
         p = self.plan
         tab = p["norm_tab"][0, layer, slot]
         ss = p["norm_tab"].stride(0)
         if p["per_sample_t"]:
-            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, gamma_batch_stride=ss, rows_per_batch=p["N"])
+            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, gamma_batch_stride=ss, rows_per_batch=p["N"], split=self.split)
         else:
-            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, step=p["step"], gamma_step_stride=ss, rows_per_batch=p["N"])
+            L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, step=p["step"], gamma_step_stride=ss, rows_per_batch=p["N"], split=self.split)
 
     def _gate_kw(self, layer, slot):
         p = self.plan
@@ -314,31 +363,35 @@ class DiTEngine:
         N, rows = p["N"], nseq * p["N"]
         hn, qkv, ao = p[f"hn_{s}"], p[f"qkv_{s}"], p[f"ao_{s}"]
         if self._fuse_rope:       # RoPE of the q and k heads inside the QKV GEMM epilogue
-            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad,
-                   rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **in_kw)
+            self._mm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad,
+                     rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **in_kw)
         else:
-            L.gemm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, compute=self.cdc, bias=A.b_in, ldo=A.n_pad, **in_kw)
+            self._mm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad, **in_kw)
             L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
                    table=p["rope"], layout=self.rope_layout)
         es = qkv.element_size()
         base = qkv.data_ptr()
         lens = p["seq_len"] if p["ragged"] else None
-        L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
+        aout = p[f"ao32_{s}"] if self.split else ao
+        L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, aout.data_ptr(),
                     strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, A.inner,
                              N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.inner),
                     B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens,
                     q_len=lens if self.zero_masked_queries else None,
-                    scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.cdc)
-        L.gemm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, compute=self.cdc, resid=x, ldo=d, ldr=d, **out_kw)
+                    scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc)
+        if self.split:
+            L.split_bf16(aout, ao, rows=rows, d=A.inner)
+        self._mm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, resid=x, ldo=d, ldr=d, **out_kw)
 
     def _ff(self, Fw: _FF, x, s, nseq, d, out_kw, in_kw={}):
         p = self.plan
         rows = nseq * p["N"]
         hn, ffh = p[f"hn_{s}"], p[f"ffh_{s}"]
-        L.gemm([(hn, d, d)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, compute=self.cdc, epilogue=L.EPI_GEGLU,
-               bias=Fw.b1, ldo=Fw.inner, **in_kw)
-        L.gemm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, compute=self.cdc, bias=Fw.b2, resid=x,
-               ldo=d, ldr=d, out_bf16=self._sh(x), **out_kw)
+        h1 = p[f"ffh32_{s}"] if self.split else ffh
+        self._mm([(hn, d, d)], Fw.w1, h1, M=rows, N=2 * Fw.inner, epilogue=L.EPI_GEGLU, bias=Fw.b1, ldo=Fw.inner, **in_kw)
+        if self.split:
+            L.split_bf16(h1, ffh, rows=rows, d=Fw.inner)
+        self._mm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, bias=Fw.b2, resid=x, ldo=d, ldr=d, out_bf16=self._sh(x), **out_kw)
 
     def _side_block(self, ly, s, src, dst, nseq, d):
         """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward."""
@@ -404,14 +457,17 @@ class DiTEngine:
         for b in range(B):
             if drop_ctx[b]:
                 cx[b] = 0                                     # x3:2058-2062
-        p["ctx"].copy_(cx.reshape(B * nc, -1))
+        if self.split:
+            L.split_bf16(cx.reshape(B * nc, -1).contiguous(), p["ctx"], rows=B * nc, d=c.ctx_dim)
+        else:
+            p["ctx"].copy_(cx.reshape(B * nc, -1))
         cm = context_mask.to(torch.bool).cpu()
         cl = cm.sum(-1).to(torch.int32)
         assert bool((cm == (torch.arange(nc)[None] < cl[:, None])).all()), "context_mask must be a prefix mask"
         p["ctx_len"].copy_(cl)
         inner = c.heads * c.dim_head
         nkv = 2 * c.depth * inner
-        L.gemm([(p["ctx"], c.ctx_dim, c.ctx_dim)], W.ctx_kv_w, p["ctx_kv"], M=B * nc, N=nkv, compute=self.cdc, ldo=nkv)
+        self._mm([(p["ctx"], c.ctx_dim, c.ctx_dim)], W.ctx_kv_w, p["ctx_kv"], M=B * nc, N=nkv, ldo=nkv)
         if self.rope_cross:                                   # A7: keys take the LAST nc table rows
             L.rope(p["ctx_kv"], rows=B * nc, row_stride=nkv, nheads=c.depth * c.heads, rows_per_batch=nc,
                    pos_offset=N - nc, table=p["rope"], layout=self.rope_layout)
@@ -427,7 +483,9 @@ class DiTEngine:
         B, Bt, T, N, D = p["B"], p["Bt"], p["T"], p["N"], c.dim
         L.linear_small(y, W.pin_wt, W.pin_b, W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
                        out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0),
-                       regs=W.regs, out_bf16=self._sh(p["xA"]))
+                       regs=W.regs, out_bf16=None if self.split else self._sh(p["xA"]))
+        if self.split:
+            L.split_bf16(p["xA"], self._sh(p["xA"]), rows=Bt * N, d=D)
 
     def forward(self, n_ctx_seqs: int | None = None):
         """Transformer.forward over the plan's Bt sequences starting from xA; result in plan['pred'].
@@ -491,17 +549,17 @@ class DiTEngine:
             wait(main, eT, eF)
             xn = p["skips"][i] if i < half else xo
             ax, at_, af_ = self._opnd(xc), self._opnd(tc_), self._opnd(fc_)
-            L.gemm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D, compute=self.cdc,
-                   epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn))
+            self._mm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D,
+                     epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn))
             if not last:
                 nxt = W.layers[i + 1]
                 hint = self.side_tile + 1 if (multi and not self.cross_on_main) else 0
                 def cross_t():
-                    L.gemm([(ax, D, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt, compute=self.cdc,
-                           epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt, tile_hint=hint)
+                    self._mm([(ax, D, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt,
+                             epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt, tile_hint=hint)
                 def cross_f():
-                    L.gemm([(ax, D, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df, compute=self.cdc,
-                           epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df, tile_hint=hint)
+                    self._mm([(ax, D, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df,
+                             epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df, tile_hint=hint)
                 if self.cross_on_main or not multi:
                     cross_t()
                     cross_f()
@@ -521,8 +579,7 @@ class DiTEngine:
                 src = xn
             else:
                 src = p["xS"]
-                L.gemm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src,
-                       M=rows, N=D, compute=self.cdc, ldo=D)
+                self._mm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src, M=rows, N=D, ldo=D)
             dst = xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
@@ -536,24 +593,27 @@ class DiTEngine:
                 self._norm_ada(x, p["hn_a"], r2, D, i, 1)
                 q2 = p["q2"]
                 if self.rope_cross and self._fuse_rope:
-                    L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad,
-                           rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N)
+                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad,
+                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N)
                 else:
-                    L.gemm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, compute=self.cdc, bias=A2.b_in, ldo=A2.n_pad)
+                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad)
                     if self.rope_cross:
                         L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
                                table=p["rope"], layout=self.rope_layout)
                 es = q2.element_size()
                 kb = p["ctx_kv"].data_ptr() + i * inner * es
                 vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
-                L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, p["ao_a"].data_ptr(),
+                aout = p["ao32_a"] if self.split else p["ao_a"]
+                L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, aout.data_ptr(),
                             strides=(A2.n_pad, nkv, nkv, A2.n_pad, inner,
                                      N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * inner),
                             B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
                             q_len=lens if self.zero_masked_queries else None,
-                            scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.cdc)
-                L.gemm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, compute=self.cdc, resid=x, ldo=D, ldr=D,
-                       epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
+                            scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc)
+                if self.split:
+                    L.split_bf16(aout, p["ao_a"], rows=r2, d=inner)
+                self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
+                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
             self._norm_ada(x, p["hn_a"], rows, D, i, 2)
             self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2)))
             if not last:
@@ -574,9 +634,8 @@ class DiTEngine:
                 tc_, fc_ = tbuf[1], fbuf[1]
             xc, xo = xo, xc
         # final norm over all rows (registers are dropped by the consumer) + to_pred (x3:1141-1143, 2083)
-        L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g)
-        L.gemm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, compute=self.cdc, bias=W.pred_b,
-               ldo=c.num_channels)
+        L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g, split=self.split)
+        self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels)
         return p["pred"]
 
     def euler_step(self, y, cfg_strength: float, remove_parallel_component: bool = False, keep_parallel_frac: float = 0.0):

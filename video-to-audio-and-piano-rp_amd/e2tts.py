@@ -148,7 +148,7 @@ class E2TTS:
         video_encoder="clip_vit",
         *,
         # ---- build-side extensions (keyword-only) ----
-        compute_dtype: str = "bf16",         # "bf16" | "fp32" (parity mode)
+        compute_dtype: str = "bf16",         # "bf16" | "fp32" (parity mode, exact-fp32 MFMA) | "bf16x3" (parity-grade split-bf16 GEMMs)
         device="cuda",
         rope_layout: str = "interleaved",
         rope_cross: bool = True,
@@ -182,6 +182,8 @@ class E2TTS:
         self.video_encoder = video_encoder
         self.training = False
         self._device = torch.device(device)
+        if compute_dtype not in ("bf16", "fp32", "bf16x3"):
+            raise ValueError(f"compute_dtype must be 'bf16', 'fp32' or 'bf16x3', got {compute_dtype!r}")
         self._compute = compute_dtype
         self._rope = (rope_layout, rope_cross)
         self._use_graph = use_graph
@@ -264,7 +266,7 @@ class E2TTS:
                                "frames_embed= or frames_encoder_fn= instead")
         if self._v2r is None:
             from .video2roll import Video2RollEngine
-            self._v2r = Video2RollEngine(self._v2r_sd, self._device, compute=self._compute)
+            self._v2r = Video2RollEngine(self._v2r_sd, self._device, compute="bf16" if self._compute == "bf16" else "fp32")
         return self._v2r.encode_frames(x, l)
 
     def _get_context(self, prompt, context, context_mask, b):
