@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the supplementary configs[3] (V2P) and configs[4] (cascade) legs")
-    ap.add_argument("--eager-roofline", action="store_true", help="time kernels with eager event pairs instead of events between graph nodes")
+    ap.add_argument("--graph-roofline", action="store_true", help="try to time kernels with events between graph nodes (not available on ROCm 7.0 torch)")
     ap.add_argument("--no-video2roll", action="store_true", help="skip the supplementary Video2Roll frame-encoder measurement (SURVEY 8f N2)")
     ap.add_argument("--no-vocoder", action="store_true", help="skip the supplementary Encodec-decoder measurement (SURVEY 8f N1)")
     ap.add_argument("--video2roll-frames", type=int, default=251, help="video frames per clip: floor(750 / 3) + 1 (x3:1913)")
@@ -212,7 +212,10 @@ def main():
         if not args.no_batched and B == 1:
             res["batched"] = batched_leg(model, cfg, cfm_steps, args, T, NC, dev)
             if not args.no_roofline:
-                hbm["clips_8"] = roofline_leg(model, L, args, hbm_only=True)
+                r8 = roofline_leg(model, L, args)
+                hbm["clips_8"] = r8.pop("hbm")
+                res["batched"]["roofline"] = {k: r8[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "launches_per_eval", "all_gemm_tflops",
+                                                                   "all_gemm_frac", "eval_kernel_ms", "kernels")}
             log("batched leg done")
         if not args.no_roofline:
             one_step()                                     # restore this run's plan (and its graph) after the batched leg
@@ -369,9 +372,8 @@ def batched_leg(model, cfg, cfm_steps, args, T, NC, dev):
 
 
 def _timed_evaluation(model, L, args, reps, shapes=False):
-    """Per-kernel time of ONE Euler evaluation of the model's current plan, kernels one at a time on one stream.
-    Preferred: the evaluation is captured in a hipGraph with an external HIP event recorded in front of every launch
-    (stream = the capture stream, i.e. the stream the kernels run on); falls back to eager event pairs."""
+    """Per-kernel time of ONE Euler evaluation of the model's current plan, kernels one at a time on one stream (the
+    production kernels, tile hints included), HIP events recorded on the stream the kernels are launched on."""
     from v2a_amd.dit import process_streams
     eng = model.engine()
     p = eng.plan
@@ -383,8 +385,8 @@ def _timed_evaluation(model, L, args, reps, shapes=False):
     torch.cuda.synchronize()
     how = "hip events between the nodes of a single-stream hipGraph (kernel + launch boundary)"
     prof = None
-    if not args.eager_roofline:
-        try:
+    if args.graph_roofline:          # needs external event nodes in captured graphs: refused by torch on ROCm 7 ("External events
+        try:                         # are disallowed in rocm"), and hipEventRecordWithFlags inside a capture invalidates it
             prof = L.KernelProfiler(shapes=shapes, external=True)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=process_streams(model.device)[2], capture_error_mode="thread_local"):
@@ -406,15 +408,24 @@ def _timed_evaluation(model, L, args, reps, shapes=False):
             torch.cuda.synchronize()
             prof = None
     if prof is None:
-        how = "eager HIP event pairs around every launch (includes the dispatch gap)"
+        # Eager launches, every one between its own pair of HIP events on the launch stream.  The GPU is first parked behind a
+        # spin kernel (torch.cuda._sleep) while the host enqueues the whole evaluation, so no interval contains host launch
+        # latency: what is measured is kernel + the two event packets around it.
+        how = "eager HIP event pairs around every launch, queue pre-filled behind a spin kernel (kernel + event packets)"
         prof = L.KernelProfiler(shapes=shapes, inner=1)
-        L.set_profiler(prof)
-        try:
-            for _ in range(reps):
-                p["step"].zero_()
+        t0 = time.perf_counter()
+        torch.cuda._sleep(10_000_000)
+        torch.cuda.synchronize()
+        cyc_per_ms = 10_000_000 / ((time.perf_counter() - t0) * 1e3)
+        for _ in range(reps):
+            p["step"].zero_()
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(cyc_per_ms * 12))          # ~12 ms: longer than the host needs to enqueue one evaluation
+            L.set_profiler(prof)
+            try:
                 eng.euler_step(y, args.cfg_strength, False)
-        finally:
-            L.set_profiler(None)
+            finally:
+                L.set_profiler(None)
     agg = prof.summary()
     y.copy_(keep)
     p["step"].zero_()
@@ -423,13 +434,13 @@ def _timed_evaluation(model, L, args, reps, shapes=False):
     return agg, how
 
 
-def roofline_leg(model, L, args, hbm_only=False):
+def roofline_leg(model, L, args):
     """`achieved` = algorithmic FLOPs (2*M*N*K per launch) / measured time of the GEMM instantiation with the most time per
     evaluation; `hbm` = algorithmic bytes / measured time of the memory-bound kernels against the 8 TB/s HBM peak.  The same
     command under `rocprofv3 --kernel-trace --stats` gives the kernel-only durations committed in profiles/."""
     reps = 3
     agg, how = _timed_evaluation(model, L, args, reps)
-    if args.shapes and not hbm_only:       # per-shape GEMM table on stderr (tuning aid)
+    if args.shapes:       # per-shape GEMM table on stderr (tuning aid)
         a2, _ = _timed_evaluation(model, L, args, reps, shapes=True)
         tot2 = sum(a["ms"] for a in a2.values())
         for k, a in sorted(a2.items(), key=lambda kv: -kv[1]["ms"]):
@@ -441,8 +452,6 @@ def roofline_leg(model, L, args, hbm_only=False):
             gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             hbm[k] = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
                       "MB_per_launch": round(a["bytes"] / a["launches"] / 1e6, 3), "achieved_GBs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
-    if hbm_only:
-        return hbm
     table, tot_ms = {}, sum(a["ms"] for a in agg.values())
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         row = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),

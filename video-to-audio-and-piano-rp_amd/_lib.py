@@ -296,6 +296,8 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
     esz = 2 if compute == BF16 else 4
     nbytes = M * K * (4 if g.a_dtype == F32 else 2) + N * K * esz + M * (N // 2 if epilogue == EPI_GEGLU else N) * out.element_size()
+    if g.tile_hint:
+        key = key[:-1] + ",tile%d>" % (g.tile_hint - 1)        # side-stream launches: tile shape chosen for running beside others
     if _prof is not None and _prof.shapes:
         key += " %dx%dx%d" % (M, N, K)
     _launch(key, 2.0 * M * N * K, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))

@@ -9,16 +9,17 @@
 // (global_load_lds_dwordx4 writes 8 rows x 128 B per wave-instruction, lane-linear) and on the fragment reads.
 //
 // K loop: 4 phases per K tile, one quadrant (16 x v_mfma_f32_16x16x32_bf16) per phase:
-//   phase      reads (this K tile t, buffer b)     LDS-DMA issued               MFMA quadrant
-//   P1         A0 (8), B0 (4)                      BH1(t+1) -> b^1              (0,0)
-//   P2         B1 (4)                              AH1(t+1) -> b^1              (0,1)
-//   P3         A1 (8)  (over A0's registers)       AH0(t+2) -> b                (1,1)
-//   P4         --                                  BH0(t+2) -> b, vmcnt(4)      (1,0)   B0 stays in registers since P1
-// Each phase is  {reads, DMA issue} s_barrier {MFMAs} s_barrier.  Every half tile is restaged two phases or more after its
-// last fragment read and read one phase or more after the counted vmcnt + barrier that retires it, which is what the
-// STAGGERED form needs: the waves of wave row 1 run one barrier behind wave row 0 (they share SIMDs pairwise), so on every
-// SIMD one wave multiplies while its partner reads LDS and issues DMA.  vmcnt is never 0 inside the loop: two half tiles
-// stay in flight across every barrier.
+//   phase      reads (this K tile t, buffer b)     LDS-DMA issued                         MFMA quadrant
+//   P1         A0 (8), B0 (4)                      --                                     (0,0)
+//   P2         B1 (4)                              AH1(t+1) -> b^1                        (0,1)
+//   P3         A1 (8)  (over A0's registers)       AH0(t+2) -> b                          (1,1)
+//   P4         --                                  BH0(t+2), BH1(t+2) -> b, vmcnt(6)      (1,0)   B0 stays in registers since P1
+// (the read-heavy phase issues no DMA and the read-free phase issues two half tiles: 12 / 6 / 10 / 4 LDS-or-DMA instructions
+// per phase instead of 14 / 6 / 10 / 2).  Each phase is  {reads, DMA issue} s_barrier {MFMAs} s_barrier.  Every half tile is
+// restaged two phases or more after its last fragment read and read one phase or more after the counted vmcnt + barrier that
+// retires it, which is what the STAGGERED form needs: the waves of wave row 1 run one barrier behind wave row 0 (they share
+// SIMDs pairwise), so on every SIMD one wave multiplies while its partner reads LDS and issues DMA.  vmcnt is never 0 inside
+// the loop: three half tiles stay in flight across every barrier.
 //
 // Dense operands only (no offset tables); up to 3 K-concatenated A segments; epilogues shared with gemm.hip.
 #include "gemm_common.h"
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-  // ---- prologue: K tile 0 whole, plus the two halves of K tile 1 the steady state would have issued already
+  // ---- prologue: K tile 0 whole, plus the three halves of K tile 1 the steady state would have issued already
   stage_a(0, 0, 0);
   stage_b(0, 0, 0);
   stage_b(1, 0, 0);
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   if (nk > 1) {
     stage_a(0, 1, 1);
     stage_b(0, 1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    stage_b(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -167,7 +169,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     // P1
     read_a(0, B);
     read_b(0, B, bf0);
-    if (t + 1 < nk) stage_b(1, t + 1, B ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     quadrant(I0{}, I0{}, bf0);
@@ -189,10 +190,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     quadrant(I1{}, I1{}, bf1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    // P4: K tile t+1 must have landed for every wave before anyone reads it (next P1 and later)
+    // P4: K tile t+1 (last piece: AH1 from P2) must have landed for every wave before anyone reads it (next P1 and later)
     if (t + 2 < nk) {
       stage_b(0, t + 2, B);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      stage_b(1, t + 2, B);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
