@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered, 2 lock-step)")
     ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
     ap.add_argument("--gemm-force-tile", type=int, default=-1, help="v2a_set_tuning: one tile configuration for every bf16 GEMM (experiment)")
+    ap.add_argument("--xcd-1x8", action="store_true", help="A/B: round-1 XCD tile order (column strips) instead of the per-shape rectangle grid")
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
@@ -117,9 +118,9 @@ def main():
     from v2a_amd import _lib as L
     from v2a_amd.synth import random_state_dict, synthetic_conditioning
 
-    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0:
+    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8:
         L.set_tuning(force_tile=args.gemm_force_tile, eight_phase=(args.gemm_8phase if args.gemm_8phase >= 0 else None),
-                     eight_phase_min_tiles=args.gemm_8phase_min_tiles)
+                     eight_phase_min_tiles=args.gemm_8phase_min_tiles, xcd_order_1x8=args.xcd_1x8)
     cfg = v2a_amd.DiTConfig()
     if args.clips_per_gpu <= 0:
         args.clips_per_gpu = 1 if world == 1 else 8

@@ -23,6 +23,10 @@ for s in "$@"; do
            TAILN=0 run side_${st}_${mt} 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --side-tile $st --gemm-force-tile $mt
            echo "--- side tile $st main tile $mt: $(grep -o '"value": [0-9.]*' gpurun_out/side_${st}_${mt}.log)"
          done ;;
+    xcd) for v in "" "--xcd-1x8" "" "--xcd-1x8"; do
+           TAILN=0 run xcd_x 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v
+           echo "--- xcd grid $v: $(grep -o '"value": [0-9.]*' gpurun_out/xcd_x.log) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/xcd_x.log | head -1)"
+         done ;;
     cross) for v in "" "--cross-on-sides"; do
            TAILN=0 run cross_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --side-tile 0 $v
            echo "--- side tile 0 $v: $(grep -o '"value": [0-9.]*' gpurun_out/cross_x.log)"
@@ -50,7 +54,7 @@ for s in "$@"; do
     bench_nocpu) run bench_nocpu 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_shapes) run bench_shapes 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --shapes ;;
     bench8) run bench8 600 python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline ;;
-    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph --no-batched --no-video2roll --no-vocoder"
+    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs ${PMC_EXTRA:-}"
          i=0
          for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
            i=$((i+1)); rm -rf /tmp/pmc$i
@@ -71,9 +75,13 @@ for s in "$@"; do
            TAILN=0 run big_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --clips-per-gpu 8
            echo "--- big $t B=8: $(grep -E 'timed' gpurun_out/big_$t.log)"
          done; unset V2A_GEMM_BIG ;;
-    prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder
+    prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
           mkdir -p gpurun_out/prof; cp /tmp/prof/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_multistream.csv ;;
-    prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched --no-video2roll --no-vocoder
+    prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+          mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
+    prof8) rm -rf /tmp/prof8; run prof8 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -- python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+          mkdir -p gpurun_out/prof; cp /tmp/prof8/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_8clips.csv ;;
+    prof1_old) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched --no-video2roll --no-vocoder
           mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
     prof_v2r) rm -rf /tmp/profv; run prof_v2r 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profv -- python bench.py --steps 1 --warmup 0 --cfm-steps 4 --no-cpu-baseline --no-roofline --no-batched
           mkdir -p gpurun_out/prof; cp /tmp/profv/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_video2roll.csv ;;

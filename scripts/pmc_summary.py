@@ -8,11 +8,11 @@ import sys
 
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
-    m = re.search(r"(gemm_bf16_dma_kernel<[^>]*>|gemm_kernel<[^>]*>|attn_\w+|dwconv_kernel|rmsnorm_kernel<[^>]*>|rope_kernel|cfg_euler\w*|"
+    m = re.search(r"(gemm_bf16_dma_kernel<[^>]*>|gemm_bf16_8ph_kernel<[^>]*>|gemm_kernel<[^>]*>|attn_\w+|dwconv_kernel|rmsnorm_kernel<[^>]*>|rope_kernel|cfg_euler\w*|"
                   r"linear_small\w*|time_cond\w*|cast_bf16\w*|step_advance\w*|apg_\w+|fill_registers\w*)", n)
     if m:
         return m.group(1)
-    m = re.search(r"N_1\d+(gemm_bf16_dma_kernel|gemm_kernel|rmsnorm_kernel|rope_kernel)I(\w+?)EEv", n)
+    m = re.search(r"N_1\d+(gemm_bf16_dma_kernel|gemm_bf16_8ph_kernel|gemm_kernel|rmsnorm_kernel|rope_kernel)I(\w+?)EEv", n)
     if m:
         return m.group(1) + "<" + m.group(2) + ">"
     return n[:70]

@@ -191,15 +191,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  // M-fastest order: the workgroups an XCD runs back to back share one W panel (the big, HBM-streamed
-  // operand: fetched into that XCD's L2 once) and sweep the M bands of the small, L2-resident A.
-  const int tn = bid / tiles_m, tm = bid % tiles_m;
+  int tm, tn;
+  tile_of_block(blockIdx.x, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[TM][TN];
@@ -388,7 +381,7 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 // (A/B on MI355X: +1..2 % at 8 clips per GPU end to end).  At one clip its 224-280 workgroups of 128 KB LDS take every CU for
 // 35-70 us: alone it is the fastest choice for the feed-forward GEMMs (774 vs 644 TF/s), beside the other two streams of the
 // sampler it costs 1.3 % end to end, and with fewer tiles the 128x256 ring kernel fills the chip better anyway.
-static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400};
+static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400, 1};
 v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 
@@ -406,7 +399,8 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 6, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
   V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
   v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,
-                               t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase};
+                               t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,
+                               t->gemm_xcd_order_1x8 ? 0 : 1};
   return V2A_OK;
 }
 
@@ -468,6 +462,21 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   // clip's result would change (in the last bits) with the batch it is sampled in; v2a_set_tuning enables it
   const v2a_detail::GemmTuning tune = v2a_detail::g_gemm_tuning;
   p.krot = tune.krot;
+  {
+    // XCD grid over the tile space: minimise A_bytes * gn + W_bytes * gm (gemm_common.h, tile_of_block); v2a_set_tuning can
+    // pin the old 1 x 8 order for A/B measurements
+    const double ab = (double)a->M * K * (a->a_dtype == V2A_F32 ? 4 : 2), wb = (double)a->N * K * (a->compute_dtype == V2A_F32 ? 4 : 2);
+    int best_gm = 1;
+    double best = ab * 8 + wb;
+    if (tune.xcd_grid) {
+      for (int gm = 2; gm <= 8; gm *= 2) {
+        const double c = ab * (8 / gm) + wb * gm;
+        if (c < best * 0.95) { best = c; best_gm = gm; }
+      }
+    }
+    p.xcd_gm = best_gm;
+    p.xcd_gn = 8 / best_gm;
+  }
   p.a_rowoff = a->a_row_offset;
   p.a_koff = a->a_ktile_offset;
   p.o_rowoff = a->out_row_offset;

@@ -42,14 +42,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  // M-fastest: the workgroups of one XCD walk the M tiles of one W panel before moving to the next panel
-  const int tn = bid / tiles_m, tm = bid % tiles_m;
+  int tm, tn;
+  tile_of_block(blockIdx.x, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[TM][TN];

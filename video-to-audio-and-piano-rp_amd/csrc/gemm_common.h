@@ -37,6 +37,7 @@ struct GemmParams {
   const int32_t* a_koff;
   const int32_t* o_rowoff;
   int32_t krot;     // start each M band's K walk at a different K tile (see the kernel)
+  int32_t xcd_gm, xcd_gn;   // the 8 XCDs as a gm x gn grid over the tile space (gm * gn == 8): see tile_of_block
 };
 
 // tile-shape selectors of the LDS-DMA bf16 kernels (v2a_set_tuning)
@@ -45,6 +46,7 @@ struct GemmTuning {
   int krot;              // K rotation (see gemm_bf16_dma_kernel)
   int use_8phase;        // 256x256 8-phase kernel for wide outputs: 0 off, 1 staggered wave rows, 2 lock-step
   int min_tiles_8phase;  // ... when the problem has at least this many 256x256 tiles
+  int xcd_grid;          // 1: XCD rectangle grid chosen per shape, 0: always 1 x 8 (every XCD walks all M of its column strip)
 };
 extern GemmTuning g_gemm_tuning;
 extern int g_dwconv_rows_per_wave;   // 4 or 8 (v2a_set_tuning)
@@ -57,6 +59,32 @@ int launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStre
 namespace {
 
 using v2a_detail::GemmParams;
+
+// Workgroup -> output tile, XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the L2 a block
+// uses), every XCD has its own 4 MB L2, and an operand panel shared by workgroups on different XCDs is fetched once per XCD.
+// The tile space (tiles_m x tiles_n) is therefore cut into a gm x gn grid of rectangles, one per XCD label: the A rows of a
+// rectangle are then pulled by gn XCDs and the W rows by gm XCDs, and the host picks (gm, gn) to minimise
+// A_bytes * gn + W_bytes * gm (wide outputs: 1 x 8, W read once; narrow ones with long K: 4 x 2 or 2 x 4).  Tiles are
+// numbered rectangle by rectangle (M-fastest inside one, so consecutive workgroups of an XCD share a W panel) and label x takes
+// the x-th contiguous chunk of that order; chunk and rectangle sizes differ by at most a few tiles, which costs locality only.
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int gm, int gn, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);      // bijective: position in the linear order
+  for (int rect = 0; rect < 8; ++rect) {
+    const int xm = rect / gn, xn = rect % gn;
+    const int m_lo = xm * tiles_m / gm, m_hi = (xm + 1) * tiles_m / gm;
+    const int n_lo = xn * tiles_n / gn, n_hi = (xn + 1) * tiles_n / gn;
+    const int hm = m_hi - m_lo, cnt = hm * (n_hi - n_lo);
+    if (L < cnt) {
+      tn = n_lo + L / hm;
+      tm = m_lo + L % hm;
+      return;
+    }
+    L -= cnt;
+  }
+  tm = tn = 0;   // unreachable: the rectangles tile the space
+}
 
 template <typename T> struct TileCfg;
 template <> struct TileCfg<bf16_t> {
