@@ -56,7 +56,7 @@ def make_model(cfg, P, compute="fp32", **kw):
                                        heads=cfg.heads, dim_head=cfg.dim_head, frames_heads=cfg.frames_heads,
                                        num_registers=cfg.num_registers, max_seq_len=cfg.max_seq_len,
                                        if_text_modules=True, if_cross_attn=True, if_audio_conv=True, if_text_conv=True),
-                      num_channels=cfg.num_channels, sampling_rate=24000, if_cond_proj_in=False,
+                      num_channels=cfg.num_channels, sampling_rate=24000, if_cond_proj_in=bool(getattr(cfg, "cond_proj_in", False)),
                       compute_dtype=compute, **kw)
     res = m.load_state_dict(P, strict=False)
     assert not res.missing_keys, res.missing_keys[:3]

@@ -33,9 +33,14 @@ def test_load_state_dict_reports_missing_and_unexpected(small):
     del sd["to_pred.bias"]
     m = v2a_amd.E2TTS(transformer=dict(dim=cfg.dim, dim_text=cfg.dim_text, dim_frames=cfg.dim_frames, depth=cfg.depth, heads=cfg.heads,
                                        frames_heads=cfg.frames_heads, num_registers=cfg.num_registers, max_seq_len=cfg.max_seq_len, if_text_conv=True),
-                      num_channels=cfg.num_channels, device="cpu")
+                      num_channels=cfg.num_channels, device="cpu", if_cond_proj_in=False)
     res = m.load_state_dict(sd, strict=False)
     assert res.missing_keys == ["to_pred.bias"]
+    # the constructor default if_cond_proj_in=True (x3:1312) registers the audio-prompt projection as well (x3:1365)
+    m2 = v2a_amd.E2TTS(transformer=dict(dim=cfg.dim, dim_text=cfg.dim_text, dim_frames=cfg.dim_frames, depth=cfg.depth, heads=cfg.heads,
+                                        frames_heads=cfg.frames_heads, num_registers=cfg.num_registers, max_seq_len=cfg.max_seq_len, if_text_conv=True),
+                       num_channels=cfg.num_channels, device="cpu")
+    assert m2.load_state_dict(dict(P), strict=False).missing_keys == ["cond_proj_in.weight", "cond_proj_in.bias"]
     assert sorted(res.unexpected_keys) == ["text_encoder2.shared.weight", "vocos.decoder.weight"]
     with pytest.raises(RuntimeError):
         m.load_state_dict(sd, strict=True)

@@ -144,3 +144,24 @@ def test_euler_is_linear_in_steps(small):
                         cfg_strength=2.0, remove_parallel_component=False)
     torch.testing.assert_close(traj[1], i["y0"] + (t[1] - t[0]) * f0, atol=1e-5, rtol=1e-5)
     assert len(traj) == 3 and torch.equal(traj[-1], y)
+
+
+def test_oracle_audio_prompt_fixture_and_properties():
+    """The audio-prompted branch (x3:2015-2035, 2196-2231, 2260-2261): the oracle reproduces its committed vectors; the prompt
+    frames come back unchanged; with lens == duration `cond` is ignored; a dropped prompt changes the result."""
+    import json, os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "sample_small_prompt.npz"), allow_pickle=False))
+    cfg = O.DiTConfig(**json.loads(str(g["meta"]))["cfg"])
+    P = O.init_params(cfg, 1234)
+    t = lambda k: torch.from_numpy(g[k])
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False)
+    y = O.sample(P, cfg, t("y0"), t("text"), t("roll"), t("ctx"), t("ctx_mask"), duration=t("duration"), cond=t("cond"), lens=t("lens"), **kw)
+    np.testing.assert_allclose(y.numpy(), g["y_prompt"], atol=1e-5)
+    for b in range(2):
+        n = int(g["lens"][b])
+        assert np.array_equal(y.numpy()[b, :n], g["cond"][b, :n])
+    assert np.abs(g["y_prompt"] - g["y_prompt_audio_drop"])[1, 20:33].max() > 1e-3 and np.abs(g["y_prompt"] - g["y_prompt_audio_drop"])[0].max() < 1e-6
+    same = O.sample(P, cfg, t("y0"), t("text"), t("roll"), t("ctx"), t("ctx_mask"), duration=t("duration"), cond=t("cond"), lens=t("duration"), **kw)
+    none = O.sample(P, cfg, t("y0"), t("text"), t("roll"), t("ctx"), t("ctx_mask"), duration=t("duration"), **kw)
+    assert torch.equal(same, none)

@@ -97,6 +97,40 @@ def test_sample_vs_golden_split_bf16(small, golden, case):
     assert err < TOL
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", TOL), ("bf16x3", TOL), ("bf16", 0.3)])
+def test_audio_prompt_branch_vs_golden(small, mode, tol):
+    """lens != duration: audio-prompted infilling (x3:2015-2035, 2196-2231, 2260-2261) against tests/golden/sample_small_prompt.npz:
+    cond shorter than the longest duration (padding), different prompt lengths, a dropped prompt, and the per-forward API."""
+    import json, os
+    from oracle import e2_cfm_oracle as O
+    from conftest import GOLDEN, make_model
+    g = dict(np.load(os.path.join(GOLDEN, "sample_small_prompt.npz"), allow_pickle=False))
+    meta = json.loads(str(g["meta"]))
+    cfg = O.DiTConfig(**meta["cfg"])
+    P = O.init_params(cfg, meta["param_seed"])
+    assert np.array_equal(P["cond_proj_in.weight"].numpy(), g["cond_proj_in_weight"])
+    m = make_model(cfg, P, mode)
+    tt = lambda k: torch.from_numpy(g[k])
+    kw = dict(y0=tt("y0"), text_embed=tt("text"), context=tt("ctx"), context_mask=tt("ctx_mask"), frames_embed=tt("roll"),
+              lens=tt("lens"), duration=tt("duration"), steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False,
+              return_raw_output=True)
+    dur, lens = g["duration"], g["lens"]
+    for key, extra in (("y_prompt", {}), ("y_prompt_audio_drop", dict(audio_drop_prompt=[False, True]))):
+        y = m.sample(tt("cond"), **kw, **extra).numpy()
+        err = max(np.abs(y[b, :dur[b]] - g[key][b, :dur[b]]).max() for b in range(2))       # frames past a clip's duration are undefined
+        print(f"audio prompt {mode} {key}: max |delta mel| = {err:.3e}")
+        assert err < tol
+        for b in range(2):
+            assert np.array_equal(y[b, :lens[b]], g["cond"][b, :lens[b]])                  # x3:2260-2261: prompt frames returned as given
+    mask = O.lens_to_mask(tt("duration"), 40)
+    for name, drop in (("pred_cond", False), ("pred_null", True)):
+        got = m.transformer_with_pred_head(tt("y0"), cond=tt("step_cond"), times=torch.tensor(0.37), mask=mask, text=tt("text"),
+                                           frames_embed=tt("roll"), context=tt("ctx"), context_mask=tt("ctx_mask"),
+                                           drop_audio_cond=drop, drop_text_cond=drop, drop_text_prompt=drop).numpy()
+        err = max(np.abs(got[b, :dur[b]] - g[name][b, :dur[b]]).max() for b in range(2))
+        assert err < tol, (name, err)
+
+
 def test_sample_half_layout_and_no_cross_rope(small, golden):
     i, g = small["inp"], golden["sample_small"]
     kw = dict(steps=4, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)

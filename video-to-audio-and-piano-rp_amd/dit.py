@@ -50,6 +50,7 @@ class DiTConfig:
     notes: int = NOTES
     max_seq_len: int = 8192
     dim_context: int | None = None
+    cond_proj_in: bool = False      # E2TTS(if_cond_proj_in=...), x3:1365: the audio-prompt projection (False in every shipped config)
 
     @property
     def ctx_dim(self):
@@ -150,6 +151,13 @@ class PackedWeights:
         self.pf_b = f32("proj_frames.bias")
         self.pred_w = pk(sd["to_pred.weight"])
         self.pred_b = f32("to_pred.bias")
+        if c.cond_proj_in:          # audio-prompt projection (x3:2034); K zero-padded to the GEMM's K granule
+            wc = sd["cond_proj_in.weight"].float()
+            self.cond_k = _ru(c.num_channels, 64)
+            wp = torch.zeros(wc.shape[0], self.cond_k)
+            wp[:, :c.num_channels] = wc
+            self.cond_w = pk(wp)
+            self.cond_b = (sd["cond_proj_in.bias"].float() if "cond_proj_in.bias" in sd else torch.zeros(wc.shape[0])).to(dev).contiguous()
         self.layers = []
         ng, gw, gb, kw, vw = [], [], [], [], []
         for i in range(c.depth):
@@ -302,6 +310,10 @@ class DiTEngine:
         ang = torch.arange(N).float()[:, None] * inv[None, :]
         p["rope"] = torch.stack((ang.cos(), ang.sin()), -1).contiguous().to(dev)            # (N, 32, 2)
         p["per_sample_t"] = False
+        p["has_cond"] = False
+        if c.cond_proj_in:          # operand of the audio-prompt GEMM: (B, N, Kp) rows incl. zero register rows; pos_emb + bias table
+            p["condbuf"] = torch.zeros(B * N, w2 * self.W.cond_k, dtype=cd, device=dev)
+            p["padd"] = e(T, D)
         # side streams: text block l+1 and frames block l+1 run beside the audio block l (see forward())
         if self.dev.type == "cuda" and self.multi_stream:
             p["st"], p["sf"], _ = process_streams(self.dev)
@@ -414,12 +426,15 @@ class DiTEngine:
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
-                drop_text=None, drop_ctx=None, dt=None):
+                drop_text=None, drop_ctx=None, dt=None, step_cond=None):
         """Everything that is constant over the Euler loop.
         text (B,T,Dt) f32 CLIP features, frames_roll (B,T,51) f32, context (B,nc,ctx) f32,
         context_mask (B,nc) bool (prefix form), t_points (S,) f32 (host or device),
         lens (B,) valid latent frames per clip or None, drop_text / drop_ctx: per-sequence
-        bool lists of length Bt / B (cfg_mode fills the null half itself)."""
+        bool lists of length Bt / B (cfg_mode fills the null half itself).
+        step_cond (B,T,C) f32 or None: the masked audio prompt of the infilling branch (x3:2228), already zeroed where dropped;
+        it enters every evaluation as x += cond_proj_in(step_cond) on the conditional half and + bias on the null half
+        (x3:2015-2035: a dropped cond is zero, the bias stays)."""
         p, c, W, dev = self.plan, self.cfg, self.W, self.dev
         B, Bt, T, N, nc, S = p["B"], p["Bt"], p["T"], p["N"], p["nc"], p["S"]
         R, D, Dt, Df = c.num_registers, c.dim, c.dim_text, c.dim_frames
@@ -458,6 +473,19 @@ class DiTEngine:
         fr = frames_roll.to(dev, torch.float32).contiguous()
         L.linear_small(fr, W.pf_wt, W.pf_b, None, p["f0"], M=B * T, K=c.notes, T=T, out_batch_stride=N * Df,
                        row_off=R, d=Df, dup=(B if Bt > B else 0))                           # x3:2069
+        # -- audio prompt (x3:2015-2035)
+        p["has_cond"] = step_cond is not None
+        if step_cond is not None:
+            assert c.cond_proj_in, "step_cond needs cond_proj_in weights (E2TTS(if_cond_proj_in=True))"
+            assert step_cond.shape == (B, T, c.num_channels)
+            cb = torch.zeros(B, N, W.cond_k, device=dev)
+            cb[:, R:, :c.num_channels] = step_cond.to(dev, torch.float32)
+            cb = cb.reshape(B * N, W.cond_k)
+            if self.split:
+                L.split_bf16(cb, p["condbuf"], rows=B * N, d=W.cond_k)
+            else:
+                p["condbuf"].copy_(cb)
+            p["padd"].copy_(W.pos_emb[:T] + W.cond_b)
         # -- cross-attention K/V of every layer from the (possibly dropped) context
         cx = context.to(dev, torch.float32).clone()
         for b in range(B):
@@ -487,9 +515,12 @@ class DiTEngine:
         """x0 = [registers ; proj_in(y) + abs_pos_emb]  (x3:2027, 957-960, 975-976) into xA."""
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, T, N, D = p["B"], p["Bt"], p["T"], p["N"], c.dim
-        L.linear_small(y, W.pin_wt, W.pin_b, W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
+        L.linear_small(y, W.pin_wt, W.pin_b, p["padd"] if p["has_cond"] else W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
                        out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0),
                        regs=W.regs, out_bf16=None if self.split else self._sh(p["xA"]))
+        if p["has_cond"]:           # conditional half: x += cond_proj_in.weight @ step_cond (the bias sits in the position table)
+            self._mm([(p["condbuf"], W.cond_k, W.cond_k)], W.cond_w, p["xA"], M=B * N, N=D, epilogue=L.EPI_RESID, resid=p["xA"],
+                     ldo=D, ldr=D, out_bf16=None if self.split else self._sh(p["xA"]))
         if self.split:
             L.split_bf16(p["xA"], self._sh(p["xA"]), rows=Bt * N, d=D)
 

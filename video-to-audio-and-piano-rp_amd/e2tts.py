@@ -113,6 +113,9 @@ def expected_state_dict_shapes(cfg: DiTConfig) -> dict[str, tuple]:
     s["to_pred.bias"] = (cfg.num_channels,)
     s["proj_frames.weight"] = (df, cfg.notes)
     s["proj_frames.bias"] = (df,)
+    if cfg.cond_proj_in:                      # x3:1365 (bias optional: cond_proj_in_bias)
+        s["cond_proj_in.weight"] = (d, cfg.num_channels)
+        s["cond_proj_in.bias"] = (d,)
     return s
 
 
@@ -170,7 +173,9 @@ class E2TTS:
         tk.pop("cond_on_time", None)
         if num_channels is None:
             raise ValueError("num_channels is required (predict.py:152)")
-        self.cfg = DiTConfig(num_channels=num_channels, **tk)
+        self.cfg = DiTConfig(num_channels=num_channels, cond_proj_in=bool(if_cond_proj_in), **tk)
+        self.cond_proj_in_bias = bool(cond_proj_in_bias)
+        self.audiocond_snr = audiocond_snr
         self.dim, self.dim_text = self.cfg.dim, self.cfg.dim_text
         self.num_channels = num_channels
         self.sampling_rate = sampling_rate
@@ -225,6 +230,9 @@ class E2TTS:
         unexpected."""
         missing, unexpected, new = [], [], {}
         for k, shp in self._shapes.items():
+            if k == "cond_proj_in.bias" and not self.cond_proj_in_bias:
+                new[k] = torch.zeros(shp)
+                continue
             if k in state_dict:
                 v = state_dict[k]
                 if tuple(v.shape) != tuple(shp):
@@ -251,9 +259,15 @@ class E2TTS:
     def engine(self) -> DiTEngine:
         if self._engine is None:
             absent = [k for k in self._shapes if k not in self._sd]
+            if any(k.startswith("cond_proj_in.") for k in absent):
+                # a checkpoint of the shipped configuration has no audio-prompt projection (predict.py:144): the sampler runs
+                # without it and the infilling branch raises, as the reference's `None(cond)` would (x3:2034)
+                absent = [k for k in absent if not k.startswith("cond_proj_in.")]
+                self.cfg.cond_proj_in = False
             if absent:
                 raise RuntimeError(f"{len(absent)} parameters were never loaded (e.g. {absent[0]}): call load_state_dict first")
-            self._engine = DiTEngine(self.cfg, self._sd, self._device, compute=self._compute,
+            self._engine = DiTEngine(self.cfg, {k: v for k, v in self._sd.items() if self.cfg.cond_proj_in or not k.startswith("cond_proj_in.")},
+                                     self._device, compute=self._compute,
                                      rope_layout=self._rope[0], rope_cross=self._rope[1])
         return self._engine
 
@@ -291,9 +305,9 @@ class E2TTS:
                                    *, context=None, context_mask=None):
         """x3:1993-2088.  x (b,n,C); times (b,) or 0-dim; mask (b,n) bool prefix mask or None;
         text (b,n,dim_text) float; frames_embed (b,n,NOTES).  Returns (b,n,C) on x.device."""
-        if cond is not None:
-            raise NotImplementedError("audio-conditioned infilling (cond != None) is not on the shipped sampling path "
-                                      "(if_cond_proj_in=False, predict.py:144; lens == duration, x3:2224-2226)")
+        if cond is not None and not self.cfg.cond_proj_in:
+            raise NotImplementedError("cond != None needs cond_proj_in (E2TTS(if_cond_proj_in=True), x3:1365): with the shipped "
+                                      "configuration (predict.py:144) the reference has no such layer either (x3:2034)")
         if self.training:
             raise NotImplementedError("training-time random condition dropping is out of scope")
         b, n, _ = x.shape
@@ -310,8 +324,14 @@ class E2TTS:
         if frames_embed is None:
             frames_embed = torch.zeros(b, n, self.cfg.notes)
         drop_ctx = [dtp or bool(video_drop_prompt is not None and video_drop_prompt[i]) for i in range(b)]
+        step_cond = None
+        if cond is not None:                                  # x3:2015-2020: dropped prompts are zeroed (in place in the reference)
+            step_cond = cond.detach().to(torch.float32).clone()
+            for i in range(b):
+                if bool(drop_audio_cond) or (audio_drop_prompt is not None and audio_drop_prompt[i]):
+                    step_cond[i] = 0
         eng.prepare(text, frames_embed, context, context_mask, times, lens=lens,
-                    drop_text=[dtc] * b, drop_ctx=drop_ctx)
+                    drop_text=[dtc] * b, drop_ctx=drop_ctx, step_cond=step_cond)
         eng.embed(x.to(self._device, torch.float32).contiguous())
         pred = eng.forward(n_ctx_seqs=b)
         out = pred[:, self.cfg.num_registers:, :].to(x.device).clone()
@@ -345,8 +365,10 @@ class E2TTS:
                audio_drop_prompt=None, video_paths=None, frames=None, midis=None,
                # build-side extensions
                y0=None, text_embed=None, context=None, context_mask=None, frames_embed=None, trajectory_out=None):
-        """x3:2127-2305.  `cond` (b, n, C) only fixes shape/device here (lens == duration on every
-        shipped call, so it is never used as audio conditioning: predict.py:261-263).
+        """x3:2127-2305.  With lens == duration (every shipped call, predict.py:261-263) `cond` (b, n, C) only fixes shape and
+        device.  With lens[0] != duration[0] it is the audio prompt of the infilling branch (x3:2196-2231, 2260-2261; needs
+        if_cond_proj_in=True): zero-padded to the longest duration, masked to lens, added through cond_proj_in at every
+        evaluation (dropped in the null pass), and returned unchanged in the first lens[b] frames.
         `trajectory_out`: optional list that receives a device copy of y at every grid point (the `trajectory` of
         x3:2255, of which the reference keeps only [-1]); test aid, adds a copy per step."""
         self.eval()
@@ -366,10 +388,6 @@ class E2TTS:
             else:
                 raise NotImplementedError("`frames` needs the Video2Roll encoder: load a checkpoint holding `video2roll_net.*`, "
                                           "or pass frames_embed= / frames_encoder_fn=")
-        if frames_embed.shape[1] < cond_seq_len:
-            pad = torch.zeros(batch, cond_seq_len - frames_embed.shape[1], cfgm.notes, dtype=frames_embed.dtype, device=frames_embed.device)
-            frames_embed = torch.cat([frames_embed, pad], 1)
-        frames_embed = frames_embed[:, :cond_seq_len]
         if lens is None:
             lens = torch.full((batch,), cond_seq_len, dtype=torch.long)
         lens = torch.as_tensor(lens).cpu().long()
@@ -395,11 +413,29 @@ class E2TTS:
             duration = torch.full((batch,), duration, dtype=torch.long)
         duration = torch.maximum(lens, torch.as_tensor(duration).cpu().long()).clamp(max=max_duration)
         assert duration.shape[0] == batch
-        if not bool((lens == duration).all()):
-            raise NotImplementedError("lens != duration (audio-prompted continuation) is not on the shipped path")
         n = int(duration.amax())
-        if n != cond_seq_len:
-            raise NotImplementedError("duration beyond cond length (padding of cond, x3:2212) is not on the shipped path")
+        if frames_embed.shape[1] < n:
+            pad = torch.zeros(batch, n - frames_embed.shape[1], cfgm.notes, dtype=frames_embed.dtype, device=frames_embed.device)
+            frames_embed = torch.cat([frames_embed, pad], 1)
+        frames_embed = frames_embed[:, :n]
+        if text_embed.shape[1] != n:
+            raise ValueError(f"text_embed has {text_embed.shape[1]} frames, the longest duration is {n}")
+        # -- audio prompt (x3:2196-2231): the reference decides on clip 0 for the whole batch (x3:2224)
+        step_cond = cond_mask = condp = None
+        if int(lens[0]) != int(duration[0]):
+            if not cfgm.cond_proj_in:
+                raise NotImplementedError("lens != duration (audio-prompted infilling) needs cond_proj_in (E2TTS(if_cond_proj_in=True), "
+                                          "x3:1365): with the shipped configuration the reference fails at x3:2034 as well")
+            if self.audiocond_snr is not None:
+                raise NotImplementedError("audiocond_snr: the reference adds fresh device noise to the prompt at every step (x3:2115-2125)")
+            condp = torch.nn.functional.pad(cond.detach().to("cpu", torch.float32)[:, :n], (0, 0, 0, max(0, n - cond_seq_len)))   # x3:2212
+            cond_mask = lens_to_mask(lens, n)[..., None]                                                            # x3:2196, 2213-2214
+            step_cond = torch.where(cond_mask, condp, torch.zeros_like(condp))                                      # x3:2228
+            for i in range(batch):                                                                                  # x3:2018-2020
+                if audio_drop_prompt is not None and audio_drop_prompt[i]:
+                    step_cond[i] = 0
+        elif n != cond_seq_len:
+            raise ValueError(f"cond has {cond_seq_len} frames but the longest duration is {n}")
         context, context_mask = self._get_context(prompt, context, context_mask, batch)
         drop_ctx = [bool(video_drop_prompt is not None and video_drop_prompt[i]) for i in range(batch)]
         # -- grid (x3:2250-2252) and noise (x3:2248)
@@ -415,12 +451,14 @@ class E2TTS:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
         eng.prepare(text_embed, frames_embed, context, context_mask, t[:-1], lens=duration,
-                    drop_ctx=drop_ctx, dt=t[1:] - t[:-1])
+                    drop_ctx=drop_ctx, dt=t[1:] - t[:-1], step_cond=step_cond)
         ev[1].record()
         self._run_steps(eng, y0, S, float(cfg_strength), bool(remove_parallel_component), trajectory_out)
         ev[2].record()
         self._phase_events = ev          # device-side phase marks of this call (no host sync here): see phase_ms()
         out = p["y"].to(out_device).clone()
+        if step_cond is not None:
+            out = torch.where(cond_mask.to(out_device), condp.to(out_device), out)        # x3:2260-2261: the prompt frames come back unchanged
         if return_raw_output:
             return out
         # -- waveform decode (x3:2270-2305), only if the caller attached a vocoder module
