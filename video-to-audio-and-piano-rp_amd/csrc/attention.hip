@@ -128,7 +128,11 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
 // NG = 1: 4 waves.  NG = 2: 8 waves, wave group g takes KV tiles g, g+2, ... of the same 64 queries (own LDS
 // ring, shared barrier) and the two partial (m, l, O) states are merged through LDS at the end: twice the
 // waves per SIMD to overlap the softmax VALU work of one wave with the MFMAs / loads of another.
-template <int NG, bool CLAMP>
+// CLAMP: 0 = plain logits, 1 = soft clamp with the online running maximum, 2 = soft clamp WITHOUT a running maximum: clamped
+// logits are bounded by +-clamp, so with clamp * log2(e) <= 100 the weights 2^v lie in [2^-100, 2^100] and their sums over any
+// realistic key count stay far inside fp32 (and bf16 keeps fp32's exponent range for the P operand): the maximum, the
+// subtraction, the rescale of O and l per tile and two wave shuffles per tile disappear from a VALU-bound loop.
+template <int NG, int CLAMP>
 __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   constexpr int TK = 64, VLD = 68;
   constexpr int K_ELEMS = TK * 64, V_ELEMS = 64 * VLD;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f;
+  float m = CLAMP == 2 ? 0.f : -INFINITY, l = 0.f;
   constexpr float LOG2E = 1.4426950408889634f;
   // zc: raw QK^T -> argument of the base-2 exponential (2x*log2e with x = scale*s/clamp), or -> log2 units w/o clamp
   const float zc = p.clamp > 0.f ? 2.0f * LOG2E * p.scale / p.clamp : p.scale * LOG2E;
@@ -231,13 +235,38 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
     //   clamp*tanh(x)*log2e = C - 2C / (2^(2x log2e) + 1),  C = clamp*log2e   -> v_exp, v_rcp, 1 fma
     //   p = 2^(t - m)                                                          -> 1 sub, v_exp
     const int j0 = (jt * NG + grp) * TK;
+    bf16x8 pf[2];
+    if constexpr (CLAMP == 2) {
+      // p = 2^(C - 2C / (2^(2x log2e) + 1)) directly; masked keys (last tile only) get weight 0
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
+          s[t][j] = __builtin_amdgcn_exp2f(fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2));
+        }
+      if (j0 + TK > kvn) {             // only the last tile can be partial (wave-uniform branch)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j0 + 16 * t + 4 * g + j >= kvn) s[t][j] = 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          l += s[t][j];
+          pf[t >> 1][(t & 1) * 4 + j] = (bf16_t)s[t][j];
+        }
+    } else {
     float tmax = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v;
-        if constexpr (CLAMP) {
+        if constexpr (CLAMP == 1) {
           const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
           v = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2);
         } else {
@@ -266,7 +295,6 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[dt][j] *= alpha;
-    bf16x8 pf[2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -275,6 +303,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
         l += pv;
         pf[t >> 1][(t & 1) * 4 + j] = (bf16_t)pv;
       }
+    }
     // ---- O^T += V^T P^T : 4 d tiles x 2 k-steps of 32 keys (permuted key order, see header)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -367,13 +396,16 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
                          a->q_batch_stride % 8 == 0 && a->k_batch_stride % 8 == 0 && a->v_batch_stride % 8 == 0 &&
                          a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
     const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
-    const bool cl = a->softclamp > 0.f;
+    // soft clamp with bounded weights (no running maximum) while 2^(clamp * log2 e) stays far inside fp32: clamp <= 69
+    const int cl = a->softclamp > 0.f ? (a->softclamp * 1.4426950408889634f <= 100.f ? 2 : 1) : 0;
     if (aligned && a->Nk > 128) {
-      if (cl) hipLaunchKernelGGL((attn_mfma_kernel<2, true>), g64, dim3(512), 0, s, p);
-      else hipLaunchKernelGGL((attn_mfma_kernel<2, false>), g64, dim3(512), 0, s, p);
+      if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<2, 2>), g64, dim3(512), 0, s, p);
+      else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<2, 1>), g64, dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((attn_mfma_kernel<2, 0>), g64, dim3(512), 0, s, p);
     } else if (aligned) {
-      if (cl) hipLaunchKernelGGL((attn_mfma_kernel<1, true>), g64, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((attn_mfma_kernel<1, false>), g64, dim3(256), 0, s, p);
+      if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<1, 2>), g64, dim3(256), 0, s, p);
+      else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<1, 1>), g64, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_mfma_kernel<1, 0>), g64, dim3(256), 0, s, p);
     }
     else
       hipLaunchKernelGGL((attn_rowlane_kernel<bf16_t>), grid, block, 0, s, p);

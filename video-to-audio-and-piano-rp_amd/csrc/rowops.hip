@@ -508,11 +508,19 @@ extern "C" int v2a_linear_small(const float* a, int64_t M, int32_t K, const floa
               (long long)M, K, T, d);
   V2A_REQUIRE(obs % 4 == 0 && (((uintptr_t)out | (uintptr_t)wt | (uintptr_t)bias | (uintptr_t)add | (uintptr_t)regs) & 15) == 0 &&
                   ((uintptr_t)out_bf16 & 7) == 0, "v2a_linear_small: 16-byte alignment");
-  constexpr int ROWS = 8;
+  // rows per block: 8 when that still yields >= 2 blocks per CU, else 2 (one clip: 98 blocks of 8 rows took 46 us per
+  // evaluation on 98 CUs; 391 blocks of 2 rows spread the same work over the chip)
   const int rows = (regs ? row_off : 0) + T;
-  dim3 grid((unsigned)((rows + ROWS - 1) / ROWS), (unsigned)(M / T)), block(256);
-  hipLaunchKernelGGL((linear_small_kernel<ROWS>), grid, block, ROWS * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
-                     T, out, obs, row_off, d, dup, regs, (bf16_t*)out_bf16);
+  const int64_t nb8 = (int64_t)((rows + 7) / 8) * (M / T);
+  if (nb8 >= 512) {
+    dim3 grid((unsigned)((rows + 7) / 8), (unsigned)(M / T)), block(256);
+    hipLaunchKernelGGL((linear_small_kernel<8>), grid, block, 8 * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
+                       T, out, obs, row_off, d, dup, regs, (bf16_t*)out_bf16);
+  } else {
+    dim3 grid((unsigned)((rows + 1) / 2), (unsigned)(M / T)), block(256);
+    hipLaunchKernelGGL((linear_small_kernel<2>), grid, block, 2 * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
+                       T, out, obs, row_off, d, dup, regs, (bf16_t*)out_bf16);
+  }
   return v2a_check_launch("v2a_linear_small");
 }
 
