@@ -609,3 +609,21 @@ def test_split_bf16_planes_and_three_segment_gemm(L):
     assert torch.equal(ys[:, :K].cpu(), sp[:, :K].cpu())                      # hi planes identical
     rec = ys[:, :K].float() + ys[:, K:].float()                              # lo may use a fused multiply-subtract: compare the sum
     assert float((rec - y32).abs().max()) < 2e-5 * float(y32.abs().max())
+
+
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 7])
+def test_gemm_tile_hint(L, hint):
+    """tile_hint picks one tile shape for the call (1: 128x256 ... 4: 64x64, 7: the 256x256 phase-interleaved kernel): the
+    result equals the automatic choice bit for bit -- the K summation order of an output element does not depend on the tile."""
+    M, N, K = 1564, 1552, 192
+    g = _g(hint * 100)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(DEV)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    ref, got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    L.gemm([(a, K, K)], w, ref, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, bias=bias, resid=resid)
+    L.gemm([(a, K, K)], w, got, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, bias=bias, resid=resid, tile_hint=hint)
+    assert torch.equal(got, ref)
+    exact = resid.double().cpu() + a.float().double().cpu() @ w.float().double().cpu().t() + bias.double().cpu()
+    torch.testing.assert_close(got.cpu().double(), exact, atol=2e-4, rtol=1e-4)
