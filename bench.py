@@ -60,7 +60,8 @@ _T0 = time.perf_counter()
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PMC_FILES = ("r01_pmc1_summary.csv", "r01_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
+PMC_FILES = ("r02_pmc1_summary.csv", "r02_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
+ROCPROF_STATS = "r02_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
 
 
 def main():
@@ -380,6 +381,7 @@ def _timed_evaluation(model, L, args, reps, shapes=False):
     p = eng.plan
     y = p["y"]
     side = (p.pop("st", None), p.pop("sf", None))     # no side streams: isolated launch durations
+    side_tile, eng.side_tile = eng.side_tile, -1      # ... of the library's stand-alone tile choices (as `--single-stream` under rocprofv3)
     keep = y.clone()
     p["step"].zero_()
     eng.euler_step(y, args.cfg_strength, False)       # warm
@@ -432,6 +434,7 @@ def _timed_evaluation(model, L, args, reps, shapes=False):
     p["step"].zero_()
     if side[0] is not None:
         p["st"], p["sf"] = side
+    eng.side_tile = side_tile
     return agg, how
 
 
@@ -468,8 +471,9 @@ def roofline_leg(model, L, args):
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     all_f = sum(a["flops"] for _, a in gem)
     all_ms = sum(a["ms"] for _, a in gem)
+    rp = rocprof_avg(dom_k, dom["flops"] / dom["launches"], peak)
     return {"bound": "mfma", "kernel": dom_k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom_k), "timing": how,
+            "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom_k), "timing": how, "rocprof": rp,
             "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2), "launches_per_eval": dom["launches"] // reps,
             "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
             "all_gemm_tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(all_f / (all_ms * 1e-3) / 1e12 / peak, 4),
@@ -549,31 +553,49 @@ def configs_leg(model, cfg, args, T, NC, dev):
     return out
 
 
+def _kernel_rows(fn, kernel_key, name_col):
+    """Rows of a committed rocprofv3 summary that belong to the LDS-DMA instantiation(s) of a bench kernel class."""
+    import csv
+    epi = {"store": "0", "sigmoid": "1", "geglu": "2", "resid": "3", "gate_resid": "4"}
+    parts = kernel_key[len("gemm<"):-1].split(",")
+    tag_e, tag_o = "Li%sE" % epi[parts[2]], ("DF16b" if parts[3] == "bf16" else "f")
+    out = []
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
+        k = r[name_col].replace("void ", "").replace("(anonymous namespace)::", "")
+        if "gemm_bf16_dma_kernel" not in k:
+            continue
+        if (k.startswith("gemm_bf16_dma_kernel<%s, %s" % (epi[parts[2]], "float" if tag_o == "f" else "__bf16"))
+                or "gemm_bf16_dma_kernelI%s%s" % (tag_e, tag_o) in k or k.startswith("gemm_bf16_dma_kernel<%s%s" % (tag_e, tag_o))):
+            out.append(r)
+    return out
+
+
+def rocprof_avg(kernel_key, flops_per_launch, peak):
+    """The same kernel class in the committed `rocprofv3 --kernel-trace --stats` summary of `bench.py --single-stream`
+    (profiles/): kernel-only duration, without the event packets the live figure includes."""
+    try:
+        rows = _kernel_rows(ROCPROF_STATS, kernel_key, "Name")
+        if not rows:
+            return None
+        best = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        us = float(best["AverageNs"]) / 1e3
+        tf = flops_per_launch / (us * 1e-6) / 1e12
+        return {"avg_us": round(us, 2), "calls": int(best["Calls"]), "achieved": round(tf, 2), "frac": round(tf / peak, 4),
+                "source": "profiles/%s (%s)" % (ROCPROF_STATS, best["Name"][:70])}
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel_key):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/ files named in PMC_FILES; FETCH_SIZE and WRITE_SIZE collected in separate passes, KB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC collection cannot run inside
     the timed bench, so this is the recorded figure for the same kernel instantiation, or None."""
-    import csv
-    epi = {"store": "0", "sigmoid": "1", "geglu": "2", "resid": "3", "gate_resid": "4"}
     try:
-        parts = kernel_key[len("gemm<"):-1].split(",")
-        tag_e, tag_o = "Li%sE" % epi[parts[2]], ("DF16b" if parts[3] == "bf16" else "f")
-        def rows(fn):
-            return list(csv.DictReader(open(os.path.join(ROOT, "profiles", fn))))
-        def pick(rs):
-            # demangled "<E, out, ...>" or mangled "ILi<E>E<out>..." names of gemm_bf16_dma_kernel
-            best = None
-            for r in rs:
-                k = r["kernel"]
-                if "gemm_bf16_dma_kernel" not in k:
-                    continue
-                ok = (k.startswith("gemm_bf16_dma_kernel<%s, %s" % (epi[parts[2]], "float" if tag_o == "f" else "__bf16"))
-                      or k.startswith("gemm_bf16_dma_kernel<%s%s" % (tag_e, tag_o)))
-                if ok and (best is None or int(r["dispatches"]) > int(best["dispatches"])):
-                    best = r
-            return best
-        f, w = pick(rows(PMC_FILES[0])), pick(rows(PMC_FILES[1]))
+        def pick(fn):
+            rs = _kernel_rows(fn, kernel_key, "kernel")
+            return max(rs, key=lambda r: int(r["dispatches"])) if rs else None
+        f, w = pick(PMC_FILES[0]), pick(PMC_FILES[1])
         if f is None or w is None:
             return None
         fetch = float(f["FETCH_SIZE"]) * 1024 * 2 / int(f["dispatches"])
