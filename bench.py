@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
     ap.add_argument("--gemm-force-tile", type=int, default=-1, help="v2a_set_tuning: one tile configuration for every bf16 GEMM (experiment)")
     ap.add_argument("--xcd-1x8", action="store_true", help="A/B: round-1 XCD tile order (column strips) instead of the per-shape rectangle grid")
+    ap.add_argument("--interleave-capture", type=int, default=-1, help="A/B: 1 = interleave the capture order of audio and side blocks")
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
@@ -141,6 +142,8 @@ def main():
     elif args.side_tile >= -1:
         model.engine().side_tile = args.side_tile
     model.engine().cross_on_main = args.cross_on_main
+    if args.interleave_capture >= 0:
+        model.engine().interleave_capture = bool(args.interleave_capture)
     log("weights packed")
     y0, text, roll, ctx, cm = synthetic_conditioning(cfg, B, T, NC, seed=1000 + rank, piano=args.v2p, device=dev)
     cm = cm.cpu()

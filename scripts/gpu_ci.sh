@@ -23,6 +23,10 @@ for s in "$@"; do
            TAILN=0 run side_${st}_${mt} 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --side-tile $st --gemm-force-tile $mt
            echo "--- side tile $st main tile $mt: $(grep -o '"value": [0-9.]*' gpurun_out/side_${st}_${mt}.log)"
          done ;;
+    ilv) for v in 0 1 0 1; do
+           TAILN=0 run ilv_x 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --interleave-capture $v
+           echo "--- interleave $v: $(grep -o '"value": [0-9.]*' gpurun_out/ilv_x.log)"
+         done ;;
     xcd) for v in "" "--xcd-1x8" "" "--xcd-1x8"; do
            TAILN=0 run xcd_x 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v
            echo "--- xcd grid $v: $(grep -o '"value": [0-9.]*' gpurun_out/xcd_x.log) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/xcd_x.log | head -1)"

@@ -94,6 +94,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+ABI_VERSION = 3          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
+
+
 def _declare(lib):
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.v2a_abi_version.restype = C.c_int
@@ -135,6 +138,9 @@ def lib():
                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the sampler.")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
+        if _lib.v2a_abi_version() != ABI_VERSION:
+            raise V2AError("libv2a_cfm.so reports ABI version %d, this binding was written for %d: rebuild (csrc/build.sh)"
+                           % (_lib.v2a_abi_version(), ABI_VERSION))
         if _lib.v2a_gemm_args_size() != C.sizeof(GemmArgs):
             raise V2AError("libv2a_cfm.so was built with sizeof(v2a_gemm_args) = %d, this binding mirrors %d bytes: rebuild "
                            "(csrc/build.sh)" % (_lib.v2a_gemm_args_size(), C.sizeof(GemmArgs)))

@@ -79,24 +79,25 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // nothing to overlap a block's load phase with.)  Algorithmic traffic: 4*d B in + 4*d B out per position.
 // ------------------------------------------------------------------------------------------
 template <int KS, int TN>
-__global__ __launch_bounds__(256, 3) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
+__global__ __launch_bounds__(256, TN == 8 ? 2 : 3) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                         const float* __restrict__ wt, const float* __restrict__ bias,
-                                                        int B, int N, int d, const int32_t* len) {
+                                                        int B, int N, int d, const int32_t* len, int P, int walkers) {
   constexpr int HALF = KS / 2;
-  constexpr int NG = (TN + KS - 1 + TN - 1) / TN;        // row groups of TN rows
+  constexpr int NG = ((TN + KS - 1 + TN - 1) / TN + 2) / 3 * 3;   // row groups of TN rows, a multiple of the 3 load buffers
   constexpr int TAPS = NG * TN;                          // taps incl. zero padding
   __shared__ __attribute__((aligned(16))) float wl[TAPS * 256];
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so flat id % 8 labels the L2 a block will
-  // use.  Give each label a contiguous range of position tiles (all channel blocks of a tile together): the k-1
-  // halo rows a tile shares with its neighbours then hit in that XCD's L2 instead of being fetched over the
-  // fabric once per tile (measured 4.7x the algorithmic bytes without this).
-  const int CB = gridDim.x, P = gridDim.y;
+  // Work item = (sequence, position tile of 4*TN outputs); a block stages its 256-channel tap block once and walks items
+  // (8 clips per GPU: 3 items per block, so the 40 KB tap stage and the block prologue are paid once per three tiles).
+  // XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so flat id % 8 labels the L2 a block uses; each label owns a
+  // contiguous range of items and its walkers take neighbouring items at the same time: the k-1 halo rows a tile shares with
+  // its neighbours hit in that XCD's L2 instead of being fetched over the fabric once per tile (4.7x the algorithmic bytes
+  // without this, measured in round 1).
+  const int CB = gridDim.x;
   const int flat = blockIdx.y * CB + blockIdx.x;
-  const int per = (P + 7) >> 3;                          // position tiles (of 4*TN) per XCD label
   const int xcd = flat & 7, slot = flat >> 3;
-  const int ptile = xcd * per + slot / CB, cblk = slot % CB;
-  const int b = blockIdx.z;
-  if (ptile >= P || slot >= per * CB) return;            // whole block
+  const int cblk = slot % CB, walker = slot / CB;        // walkers per XCD label = `walkers`
+  const int items = P * B, ipx = (items + 7) >> 3;       // items per XCD label
+  if (walker >= walkers) return;                         // whole block (grid padding)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: row tests become scalar
   const int c4 = cblk * 64 + lane;                       // float4 channel group of this lane
@@ -111,70 +112,79 @@ __global__ __launch_bounds__(256, 3) void dwconv_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(wl + i * 4) = w;
   }
   __syncthreads();
-
-  const int n0 = (ptile * 4 + wave) * TN;                // wave-uniform
-  const int L = len ? min(len[b], N) : N;
   const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * cc);
-  f32x4 acc[TN], win[TN];
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    acc[t] = bv;
-    win[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // row base is wave-uniform (SGPR), the lane contributes a constant 32-bit byte offset: no vector address math
-  const char* xrow0 = reinterpret_cast<const char*>(x + (int64_t)b * N * d);
   const uint32_t loff = (uint32_t)cc * 16u;
   const float* wlane = wl + lane * 4;
-  f32x4 rowsA[TN], rowsB[TN];
-  auto load_group = [&](int g, f32x4 (&dst)[TN]) {
+
+  for (int it = walker; it < ipx; it += walkers) {
+    const int item = xcd * ipx + it;
+    if (item >= items) break;
+    const int b = item / P, ptile = item % P;
+    const int n0 = (ptile * 4 + wave) * TN;              // wave-uniform
+    const int L = len ? min(len[b], N) : N;
+    f32x4 acc[TN], win[TN];
 #pragma unroll
-    for (int r = 0; r < TN; ++r) {
-      const int pc = min(max(n0 - HALF + g * TN + r, 0), N - 1);   // clamped into the sequence; the 0/1 factor below zeroes it
-      dst[r] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)pc * d * 4 + loff);
+    for (int t = 0; t < TN; ++t) {
+      acc[t] = bv;
+      win[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  };
-  auto group = [&](int g, const f32x4 (&cur)[TN]) {
+    // row base is wave-uniform (SGPR), the lane contributes a constant 32-bit byte offset: no vector address math
+    const char* xrow0 = reinterpret_cast<const char*>(x + (int64_t)b * N * d);
+    f32x4 rowsA[TN], rowsB[TN], rowsC[TN];
+    auto load_group = [&](int g, f32x4 (&dst)[TN]) {
 #pragma unroll
-    for (int r = 0; r < TN; ++r) {
-      win[r] = *reinterpret_cast<const f32x4*>(wlane + (g * TN + r) * 256);
-      const int pos = n0 - HALF + g * TN + r;            // wave-uniform
-      // zero padding and masked rows contribute nothing: a scalar branch around the row's FMAs (a 0/1 factor on the row
-      // costs 4 multiplies per row and made the vectoriser pack values ACROSS rows, waiting on every load right after
-      // its issue); whole-vector expressions keep the arithmetic as v_pk_fma_f32
-      if (pos >= 0 && pos < L) {
-        const f32x4 v = cur[r];
+      for (int r = 0; r < TN; ++r) {
+        const int pc = min(max(n0 - HALF + g * TN + r, 0), N - 1);   // clamped into the sequence; skipped below if outside
+        dst[r] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)pc * d * 4 + loff);
+      }
+    };
+    auto group = [&](int g, const f32x4 (&cur)[TN]) {
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[t] = win[(r - t + TN) % TN] * v + acc[t];
+      for (int r = 0; r < TN; ++r) {
+        win[r] = *reinterpret_cast<const f32x4*>(wlane + (g * TN + r) * 256);
+        const int pos = n0 - HALF + g * TN + r;          // wave-uniform
+        // zero padding and masked rows contribute nothing: a scalar branch around the row's FMAs (a 0/1 factor on the row
+        // costs 4 multiplies per row and made the vectoriser pack values ACROSS rows, waiting on every load right after
+        // its issue); whole-vector expressions keep the arithmetic as v_pk_fma_f32
+        if (pos >= 0 && pos < L) {
+          const f32x4 v = cur[r];
+#pragma unroll
+          for (int t = 0; t < TN; ++t) acc[t] = win[(r - t + TN) % TN] * v + acc[t];
+        }
+      }
+    };
+    // two row groups in flight ahead of the one being multiplied (three register buffers, loop unrolled by three)
+    load_group(0, rowsA);
+    load_group(1, rowsB);
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 3) {
+      load_group(g + 2, rowsC);
+      group(g, rowsA);
+      if (g + 3 < NG) load_group(g + 3, rowsA);
+      group(g + 1, rowsB);
+      if (g + 4 < NG) load_group(g + 4, rowsB);
+      group(g + 2, rowsC);
+    }
+    if (cok) {
+      char* orow0 = reinterpret_cast<char*>(out + (int64_t)b * N * d);
+      // the unmasked centre rows for the residual (x3:1082: conv(x, mask) + x) come back from L1/L2 here rather than
+      // being held in 32 registers through the tap loop
+      f32x4 center[TN];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) center[t] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)min(n0 + t, N - 1) * d * 4 + loff);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int n = n0 + t;
+        if (n < N) {
+          f32x4 o = center[t];
+          if (n < L) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += silu_f(acc[t][j]);
+          }
+          *reinterpret_cast<f32x4*>(orow0 + (int64_t)n * d * 4 + loff) = o;
+        }
       }
     }
-  };
-  load_group(0, rowsA);
-#pragma unroll 1
-  for (int g = 0; g < NG; g += 2) {
-    if (g + 1 < NG) load_group(g + 1, rowsB);
-    group(g, rowsA);
-    if (g + 1 < NG) {
-      if (g + 2 < NG) load_group(g + 2, rowsA);
-      group(g + 1, rowsB);
-    }
-  }
-  if (!cok) return;
-  char* orow0 = reinterpret_cast<char*>(out + (int64_t)b * N * d);
-  // the unmasked centre rows for the residual (x3:1082: conv(x, mask) + x) come back from L1/L2 here rather than
-  // being held in 32 registers through the tap loop
-  f32x4 center[TN];
-#pragma unroll
-  for (int t = 0; t < TN; ++t) center[t] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)min(n0 + t, N - 1) * d * 4 + loff);
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const int n = n0 + t;
-    if (n >= N) break;
-    f32x4 o = center[t];
-    if (n < L) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] += silu_f(acc[t][j]);
-    }
-    *reinterpret_cast<f32x4*>(orow0 + (int64_t)n * d * 4 + loff) = o;
   }
 }
 
@@ -475,11 +485,15 @@ extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float*
   V2A_REQUIRE(d % 4 == 0 && B > 0 && N > 0, "v2a_dwconv: B=%d N=%d d=%d", B, N, d);
   const int TN = v2a_detail::g_dwconv_rows_per_wave;
   const int cb = (d / 4 + 63) / 64;                      // 256-channel blocks
-  // grid.y counts groups of 4 position tiles, padded to a multiple of 8 so every XCD label owns a whole range
-  const int P = (N + 4 * TN - 1) / (4 * TN);
-  dim3 grid(cb, ((P + 7) / 8) * 8, B), block(256);
-  if (TN == 8) hipLaunchKernelGGL((dwconv_kernel<31, 8>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
-  else hipLaunchKernelGGL((dwconv_kernel<31, 4>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len);
+  const int P = (N + 4 * TN - 1) / (4 * TN);             // position tiles of 4 waves x TN outputs
+  const int items = P * B, ipx = (items + 7) / 8;        // work items, items per XCD label
+  // walkers per XCD label: one per item until ~4 resident blocks per CU (LDS: 40 KB each) are reached, then blocks walk items
+  int walkers = ipx;
+  const int cap = (4 * 256 / 8 + cb - 1) / cb;
+  if (walkers > cap) walkers = cap;
+  dim3 grid(cb, walkers * 8), block(256);
+  if (TN == 8) hipLaunchKernelGGL((dwconv_kernel<31, 8>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
+  else hipLaunchKernelGGL((dwconv_kernel<31, 4>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
   return v2a_check_launch("v2a_dwconv_silu_residual");
 }
 

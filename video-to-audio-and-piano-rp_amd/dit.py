@@ -235,6 +235,9 @@ class DiTEngine:
         self.side_tile = 0 if multi_stream else -1
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
+        # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
+        # sides {norm, feed-forward} instead of audio block, text block, frames block
+        self.interleave_capture = False
         # RoPE rides in the QKV GEMM epilogue when pairs are lane-local (interleaved layout, bf16 DMA kernel)
         self._fuse_rope = compute != "fp32" and rope_layout == "interleaved"
         assert cfg.dim_head == 64, "kernels are built for dim_head = 64 (x3:717)"
@@ -411,18 +414,23 @@ class DiTEngine:
         (8 clips: text feed-forward 325 us on the 256x256 kernel against 556 us on forced 128x256 tiles)."""
         return self.side_tile + 1 if (self.side_tile >= 0 and self.plan["rows"] <= 3200) else 0
 
-    def _side_block(self, ly, s, src, dst, nseq, d):
-        """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward."""
+    def _side_block(self, ly, s, src, dst, nseq, d, parts=(0, 1, 2)):
+        """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward.  `parts` selects
+        0 = conv + norm, 1 = attention, 2 = norm + feed-forward, so that the caller can interleave the CAPTURE order of the
+        two side blocks and the audio block (a replayed graph hands kernels to the queues in capture order)."""
         p = self.plan
         N, rows = p["N"], nseq * p["N"]
         lens = p["seq_len"] if p["ragged"] else None
         cv = ly[f"{s}_conv"]
         hint = dict(tile_hint=self._side_hint())
-        L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
-        self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g1"])
-        self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
-        self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g2"])
-        self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
+        if 0 in parts:
+            L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
+            self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g1"])
+        if 1 in parts:
+            self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
+        if 2 in parts:
+            self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g2"])
+            self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
@@ -624,6 +632,16 @@ class DiTEngine:
             x = dst
             self._norm_ada(x, p["hn_a"], rows, D, i, 0)
             self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0)))
+            if not last and self.interleave_capture:
+                for part in (0, 1):
+                    with _On(st):
+                        if part == 0:
+                            wait(st, eX)
+                        self._side_block(nxt, "t", tbuf[0], tbuf[1], Bt, Dt, (part,))
+                    with _On(sf):
+                        if part == 0:
+                            wait(sf, eX)
+                        self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df, (part,))
             if nctx > 0:
                 A2 = ly["a_attn2"]
                 r2 = nctx * N
@@ -660,13 +678,16 @@ class DiTEngine:
                 # block in program order: a replayed hipGraph hands its kernels to the queues in capture order (a few us
                 # each), so whatever is captured first is submitted first -- with the side blocks in front, the audio
                 # stream (the critical path) sat idle for ~75 us per layer until 18 side kernels had been handed over.
+                rest = (2,) if self.interleave_capture else (0, 1, 2)
                 with _On(st):
-                    wait(st, eX)
-                    self._side_block(nxt, "t", tbuf[0], tbuf[1], Bt, Dt)
+                    if not self.interleave_capture:
+                        wait(st, eX)
+                    self._side_block(nxt, "t", tbuf[0], tbuf[1], Bt, Dt, rest)
                     eT = rec(st)
                 with _On(sf):
-                    wait(sf, eX)
-                    self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df)
+                    if not self.interleave_capture:
+                        wait(sf, eX)
+                    self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df, rest)
                     eF = rec(sf)
                 tc_, fc_ = tbuf[1], fbuf[1]
             xc, xo = xo, xc
