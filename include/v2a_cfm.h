@@ -131,7 +131,7 @@ typedef struct v2a_tuning {
   int32_t gemm_k_rotation;        /* 1: M bands that share a W panel start their K walk at different K tiles (changes fp32 summation order with M) */
   int32_t gemm_8phase;            /* 256x256 phase-interleaved kernel for wide outputs (N >= 2048): 0 off, 1 on (staggered wave rows), 2 on (lock-step) */
   int32_t gemm_8phase_min_tiles;  /* ... when the problem yields at least this many 256x256 tiles (0 = 400) */
-  int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass, 4 or 8 (0 = default) */
+  int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass, 4, 6 or 8 (0 = default) */
   int32_t gemm_xcd_order_1x8;     /* 1: every XCD walks whole column strips of the tile space (the round-1 order) instead of the
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t reserved[2];

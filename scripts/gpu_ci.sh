@@ -65,6 +65,12 @@ for s in "$@"; do
            run pmc$i 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc$i -- $B || true
            python scripts/pmc_summary.py /tmp/pmc$i gpurun_out/pmc${i}_summary.csv
          done ;;
+    pmcdw) i=0
+         for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" "SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" "SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
+           i=$((i+1)); rm -rf /tmp/pmcdw$i
+           TAILN=3 run pmcdw$i 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmcdw$i -- python scripts/probes/dwconv_probe.py ${DW_ARGS:-16 782 1024 0} || true
+           python scripts/pmc_summary.py /tmp/pmcdw$i gpurun_out/pmcdw${i}_summary.csv || true
+         done ;;
     bench2) V2A_BENCH_BACKEND=gloo run bench2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 ;;
     batch) for b in 2 4 8; do
              TAILN=0 run batch_$b 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --clips-per-gpu $b

@@ -66,10 +66,10 @@ def test_adaptive_rmsnorm_golden(L, small, golden):
 
 
 # -------------------------------------------------------------------------------- dwconv
-@pytest.mark.parametrize("tn", [4, 8])
+@pytest.mark.parametrize("tn", [4, 6, 8])
 @pytest.mark.parametrize("N,d,lens", [(44, 128, [44, 30]), (782, 512, None), (7, 64, [7, 3]), (100, 1280, [100, 33]), (782, 1024, [782, 1])])
 def test_dwconv(L, N, d, lens, tn):
-    """Both position-tile sizes of the kernel (4 / 8 outputs per wave pass); edge tiles, masked tails, a 1-frame clip."""
+    """All position-tile sizes of the kernel (4 / 6 / 8 outputs per wave pass); edge tiles, masked tails, a 1-frame clip."""
     B = 2
     x = torch.randn(B, N, d, generator=_g(N))
     w = torch.randn(d, 1, 31, generator=_g(N + 1)) / math.sqrt(31)

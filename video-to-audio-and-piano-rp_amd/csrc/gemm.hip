@@ -393,7 +393,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
     v2a_detail::g_dwconv_rows_per_wave = 4;
     return V2A_OK;
   }
-  V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 8, "v2a_set_tuning: dwconv_rows_per_wave %d",
+  V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6 || t->dwconv_rows_per_wave == 8, "v2a_set_tuning: dwconv_rows_per_wave %d",
               t->dwconv_rows_per_wave);
   v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave ? t->dwconv_rows_per_wave : 4;
   V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 6, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);

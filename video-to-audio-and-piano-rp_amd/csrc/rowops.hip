@@ -79,12 +79,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // nothing to overlap a block's load phase with.)  Algorithmic traffic: 4*d B in + 4*d B out per position.
 // ------------------------------------------------------------------------------------------
 template <int KS, int TN>
-__global__ __launch_bounds__(256, TN == 8 ? 2 : 3) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
+__global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                         const float* __restrict__ wt, const float* __restrict__ bias,
                                                         int B, int N, int d, const int32_t* len, int P, int walkers) {
   constexpr int HALF = KS / 2;
   constexpr int NG = ((TN + KS - 1 + TN - 1) / TN + 2) / 3 * 3;   // row groups of TN rows, a multiple of the 3 load buffers
-  constexpr int TAPS = NG * TN;                          // taps incl. zero padding
+  constexpr int TAPS = NG * TN;                          // tap rows in LDS: the k real taps, zero rows for the window slots past them
   __shared__ __attribute__((aligned(16))) float wl[TAPS * 256];
   // Work item = (sequence, position tile of 4*TN outputs); a block stages its 256-channel tap block once and walks items
   // (8 clips per GPU: 3 items per block, so the 40 KB tap stage and the block prologue are paid once per three tiles).
@@ -130,40 +130,74 @@ __global__ __launch_bounds__(256, TN == 8 ? 2 : 3) void dwconv_kernel(const floa
     }
     // row base is wave-uniform (SGPR), the lane contributes a constant 32-bit byte offset: no vector address math
     const char* xrow0 = reinterpret_cast<const char*>(x + (int64_t)b * N * d);
+    const int64_t stride = (int64_t)d * 4;
     f32x4 rowsA[TN], rowsB[TN], rowsC[TN];
-    auto load_group = [&](int g, f32x4 (&dst)[TN]) {
+    // two row groups in flight ahead of the one being multiplied (three register buffers, loop unrolled by three)
+    if (n0 >= HALF && n0 - HALF + NG * TN <= L) {
+      // interior tile (all but the first and last ~4 wave tiles of a sequence): every row of the window is inside the valid
+      // part of the sequence -- no clamps, no per-row tests, the load address is a scalar pointer stepped by the row stride
+      const char* lp = xrow0 + (int64_t)(n0 - HALF) * stride;
+      const float* wp = wlane;
+      auto load_group = [&](f32x4 (&dst)[TN]) {
 #pragma unroll
-      for (int r = 0; r < TN; ++r) {
-        const int pc = min(max(n0 - HALF + g * TN + r, 0), N - 1);   // clamped into the sequence; skipped below if outside
-        dst[r] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)pc * d * 4 + loff);
-      }
-    };
-    auto group = [&](int g, const f32x4 (&cur)[TN]) {
+        for (int r = 0; r < TN; ++r) dst[r] = *reinterpret_cast<const f32x4*>(lp + r * stride + loff);
+        lp += TN * stride;
+      };
+      auto group = [&](const f32x4 (&cur)[TN]) {
 #pragma unroll
-      for (int r = 0; r < TN; ++r) {
-        win[r] = *reinterpret_cast<const f32x4*>(wlane + (g * TN + r) * 256);
-        const int pos = n0 - HALF + g * TN + r;          // wave-uniform
-        // zero padding and masked rows contribute nothing: a scalar branch around the row's FMAs (a 0/1 factor on the row
-        // costs 4 multiplies per row and made the vectoriser pack values ACROSS rows, waiting on every load right after
-        // its issue); whole-vector expressions keep the arithmetic as v_pk_fma_f32
-        if (pos >= 0 && pos < L) {
+        for (int r = 0; r < TN; ++r) {
+          win[r] = *reinterpret_cast<const f32x4*>(wp + r * 256);
           const f32x4 v = cur[r];
 #pragma unroll
           for (int t = 0; t < TN; ++t) acc[t] = win[(r - t + TN) % TN] * v + acc[t];
         }
-      }
-    };
-    // two row groups in flight ahead of the one being multiplied (three register buffers, loop unrolled by three)
-    load_group(0, rowsA);
-    load_group(1, rowsB);
+        wp += TN * 256;
+      };
+      load_group(rowsA);
+      load_group(rowsB);
 #pragma unroll 1
-    for (int g = 0; g < NG; g += 3) {
-      load_group(g + 2, rowsC);
-      group(g, rowsA);
-      if (g + 3 < NG) load_group(g + 3, rowsA);
-      group(g + 1, rowsB);
-      if (g + 4 < NG) load_group(g + 4, rowsB);
-      group(g + 2, rowsC);
+      for (int g = 0; g < NG; g += 3) {
+        load_group(rowsC);
+        group(rowsA);
+        if (g + 3 < NG) load_group(rowsA);
+        group(rowsB);
+        if (g + 4 < NG) load_group(rowsB);
+        group(rowsC);
+      }
+    } else {
+      auto load_group = [&](int g, f32x4 (&dst)[TN]) {
+#pragma unroll
+        for (int r = 0; r < TN; ++r) {
+          const int pc = min(max(n0 - HALF + g * TN + r, 0), N - 1);   // clamped into the sequence; skipped below if outside
+          dst[r] = *reinterpret_cast<const f32x4*>(xrow0 + pc * stride + loff);
+        }
+      };
+      auto group = [&](int g, const f32x4 (&cur)[TN]) {
+#pragma unroll
+        for (int r = 0; r < TN; ++r) {
+          win[r] = *reinterpret_cast<const f32x4*>(wlane + (g * TN + r) * 256);
+          const int pos = n0 - HALF + g * TN + r;          // wave-uniform
+          // zero padding and masked rows contribute nothing: a scalar branch around the row's FMAs (a 0/1 factor on the row
+          // costs 4 multiplies per row and made the vectoriser pack values ACROSS rows, waiting on every load right after
+          // its issue); whole-vector expressions keep the arithmetic as v_pk_fma_f32
+          if (pos >= 0 && pos < L) {
+            const f32x4 v = cur[r];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = win[(r - t + TN) % TN] * v + acc[t];
+          }
+        }
+      };
+      load_group(0, rowsA);
+      load_group(1, rowsB);
+#pragma unroll 1
+      for (int g = 0; g < NG; g += 3) {
+        load_group(g + 2, rowsC);
+        group(g, rowsA);
+        if (g + 3 < NG) load_group(g + 3, rowsA);
+        group(g + 1, rowsB);
+        if (g + 4 < NG) load_group(g + 4, rowsB);
+        group(g + 2, rowsC);
+      }
     }
     if (cok) {
       char* orow0 = reinterpret_cast<char*>(out + (int64_t)b * N * d);
@@ -171,17 +205,18 @@ __global__ __launch_bounds__(256, TN == 8 ? 2 : 3) void dwconv_kernel(const floa
       // being held in 32 registers through the tap loop
       f32x4 center[TN];
 #pragma unroll
-      for (int t = 0; t < TN; ++t) center[t] = *reinterpret_cast<const f32x4*>(xrow0 + (int64_t)min(n0 + t, N - 1) * d * 4 + loff);
+      for (int t = 0; t < TN; ++t) center[t] = *reinterpret_cast<const f32x4*>(xrow0 + min(n0 + t, N - 1) * stride + loff);
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         const int n = n0 + t;
         if (n < N) {
           f32x4 o = center[t];
           if (n < L) {
+            // x * sigmoid(x) with v_exp + v_rcp (2 ulp; an IEEE division is ten more instructions per value)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += silu_f(acc[t][j]);
+            for (int j = 0; j < 4; ++j) o[j] += acc[t][j] * __builtin_amdgcn_rcpf(1.0f + __expf(-acc[t][j]));
           }
-          *reinterpret_cast<f32x4*>(orow0 + (int64_t)n * d * 4 + loff) = o;
+          *reinterpret_cast<f32x4*>(orow0 + n * stride + loff) = o;
         }
       }
     }
@@ -487,12 +522,14 @@ extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float*
   const int cb = (d / 4 + 63) / 64;                      // 256-channel blocks
   const int P = (N + 4 * TN - 1) / (4 * TN);             // position tiles of 4 waves x TN outputs
   const int items = P * B, ipx = (items + 7) / 8;        // work items, items per XCD label
-  // walkers per XCD label: one per item until ~4 resident blocks per CU (LDS: 40 KB each) are reached, then blocks walk items
-  int walkers = ipx;
-  const int cap = (4 * 256 / 8 + cb - 1) / cb;
-  if (walkers > cap) walkers = cap;
+  // walkers per XCD label: one per item until the resident blocks per CU (registers: 3 at 4 rows per wave, else 2) are reached,
+  // then blocks walk items in `rounds` equal rounds
+  const int cap = max(1, (TN == 4 ? 3 : 2) * 256 / 8 / cb);
+  const int rounds = (ipx + cap - 1) / cap;
+  const int walkers = (ipx + rounds - 1) / rounds;
   dim3 grid(cb, walkers * 8), block(256);
   if (TN == 8) hipLaunchKernelGGL((dwconv_kernel<31, 8>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
+  else if (TN == 6) hipLaunchKernelGGL((dwconv_kernel<31, 6>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
   else hipLaunchKernelGGL((dwconv_kernel<31, 4>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
   return v2a_check_launch("v2a_dwconv_silu_residual");
 }

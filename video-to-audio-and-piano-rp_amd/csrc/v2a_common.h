@@ -54,7 +54,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // branchy polynomial; used where the result is rounded to bf16 anyway.
 __device__ __forceinline__ float gelu_fast_f(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn is a ten-instruction IEEE division
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erfz = 1.0f - poly * __expf(-z * z);
   return 0.5f * x * (1.0f + copysignf(erfz, x));
