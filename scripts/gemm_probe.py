@@ -3,7 +3,8 @@
 of back-to-back launches on random data (interleaved rounds, best of 5: rule 24 of the CDNA guide).
 
 Tuning aid.  Tile configurations are selected with v2a_set_tuning: 0 = 128x256, 1 = 128x128, 2 = 128x64, 3 = 64x64,
-5 = 256x256 (2-deep ring), 6 = 256x256 8-phase (staggered), 7 = 256x256 8-phase (lock-step), -1 = automatic.
+5 = 256x256 (2-deep ring), 6 = 256x256 8-phase (staggered), 7 = 256x256 8-phase (lock-step), 17 / 18 = 64x128 / 64x64 with a
+6-deep ring, -1 = automatic.
 usage: python scripts/gemm_probe.py [--tiles 0,1,3,6,7] [--epi resid|geglu|store] 1564x1024x1024 1564x8192x1024 ...
 """
 import os
@@ -24,6 +25,8 @@ def set_cfg(t):
         _lib.set_tuning(force_tile=6, eight_phase=1)
     elif t == 7:
         _lib.set_tuning(force_tile=6, eight_phase=2)
+    elif t >= 17:                       # 17 / 18: 64x128 / 64x64 tiles with the 6-deep ring
+        _lib.set_tuning(force_tile=t - 10)
     else:
         _lib.set_tuning(force_tile=t)
 

@@ -71,6 +71,11 @@ for s in "$@"; do
            TAILN=3 run pmcdw$i 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmcdw$i -- python scripts/probes/dwconv_probe.py ${DW_ARGS:-16 782 1024 0} || true
            python scripts/pmc_summary.py /tmp/pmcdw$i gpurun_out/pmcdw${i}_summary.csv || true
          done ;;
+    maintile) SW="${MAIN_SWEEP:--1 1 2 7}"
+         for v in $SW; do
+           TAILN=0 run mt_$v 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --main-tile $v
+           echo "--- main_tile=$v: $(grep -o '"value": [0-9.]*' gpurun_out/mt_$v.log | head -1)"
+         done ;;
     bench2) V2A_BENCH_BACKEND=gloo run bench2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 ;;
     batch) for b in 2 4 8; do
              TAILN=0 run batch_$b 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --clips-per-gpu $b

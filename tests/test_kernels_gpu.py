@@ -611,9 +611,10 @@ def test_split_bf16_planes_and_three_segment_gemm(L):
     assert float((rec - y32).abs().max()) < 2e-5 * float(y32.abs().max())
 
 
-@pytest.mark.parametrize("hint", [1, 2, 3, 4, 7])
+@pytest.mark.parametrize("hint", [1, 2, 3, 4, 7, 8, 9])
 def test_gemm_tile_hint(L, hint):
-    """tile_hint picks one tile shape for the call (1: 128x256 ... 4: 64x64, 7: the 256x256 phase-interleaved kernel): the
+    """tile_hint picks one tile shape for the call (1: 128x256 ... 4: 64x64, 7: the 256x256 phase-interleaved kernel, 8 / 9: 64x128 /
+    64x64 with the 6-deep ring): the
     result equals the automatic choice bit for bit -- the K summation order of an output element does not depend on the tile."""
     M, N, K = 1564, 1552, 192
     g = _g(hint * 100)
@@ -627,3 +628,27 @@ def test_gemm_tile_hint(L, hint):
     assert torch.equal(got, ref)
     exact = resid.double().cpu() + a.float().double().cpu() @ w.float().double().cpu().t() + bias.double().cpu()
     torch.testing.assert_close(got.cpu().double(), exact, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("hint", [8, 9])
+@pytest.mark.parametrize("K", [64, 128, 320, 384, 448, 832, 1024])
+def test_gemm_deep_ring_k_tails(L, hint, K):
+    """6-deep ring (64x128 / 64x64 tiles): every length of the K loop's tail relative to the ring (1 .. 16 K tiles), three
+    A segments, ragged M and N edges, the gated-residual epilogue -- bit for bit what the 3-deep 64x64 kernel gives."""
+    M, N = 333, 456
+    g = _g(K + hint)
+    ks = [K] if K < 192 else [64, K - 128, 64]
+    segs = [torch.randn(M, k, generator=g).bfloat16().to(DEV) for k in ks]
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(DEV)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    gate = torch.randn(1, N, generator=g).to(DEV)
+    kw = dict(M=M, N=N, compute=L.BF16, epilogue=L.EPI_GATE_RESID, bias=bias, resid=resid, gate=gate, gate_step_stride=0,
+              gate_batch_stride=0, rows_per_batch=M)
+    ref, got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    L.gemm([(a, k, k) for a, k in zip(segs, ks)], w, ref, tile_hint=4, **kw)
+    L.gemm([(a, k, k) for a, k in zip(segs, ks)], w, got, tile_hint=hint, **kw)
+    assert torch.equal(got, ref)
+    acat = torch.cat([a.float().cpu() for a in segs], 1).double()
+    exact = resid.double().cpu() + gate.double().cpu() * (acat @ w.float().double().cpu().t() + bias.double().cpu())
+    torch.testing.assert_close(got.cpu().double(), exact, atol=5e-4, rtol=1e-4)

@@ -171,6 +171,19 @@ int dispatch_epi(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 // image linear per wave, XOR swizzle applied to the per-lane SOURCE chunk: rule 21 of the CDNA guide),
 // two K tiles stay in flight across the single raw s_barrier of each iteration (counted vmcnt),
 // and no VGPRs or ds_writes are spent on staging.
+// Wait until at most min(J, younger) of the youngest K tiles' DMAs (LPW instructions per wave each) are still outstanding:
+// the counted s_waitcnt needs an immediate, so the tail of the K loop walks down a chain of them.
+template <int J, int LPW>
+__device__ __forceinline__ void ring_wait(int younger) {
+  if constexpr (J == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    static_assert(J * LPW <= 63, "vmcnt is a 6-bit field");
+    if (younger >= J) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(J * LPW) : "memory");
+    else ring_wait<J - 1, LPW>(younger);
+  }
+}
+
 template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParams p) {
   constexpr int NW = WGM * WGN;
@@ -276,8 +289,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   EpiPrefetch<EPI, TM, WN, PF> pf;
   if (p.vec_epi) pf.load(p, m0 + wm * WM, n0 + wn * WN, lane);
   const int nk = p.K / 64;
-  // ring of NST stages (3: two tiles in flight while one is computed; 2: the 256x256 tile, whose 64 KB stages leave
-  // room for only two)
+  // ring of NST stages, NST - 1 K tiles in flight while one is computed (3 by default; 2: the 256x256 tile, whose 64 KB
+  // stages leave room for only two; 6: the small tiles of a one-clip launch, which has at most one workgroup per CU and is
+  // bound by DMA latency x bytes in flight -- a K step of the 3-deep 64x64 ring took 1020 cycles for 128 cycles of MFMA)
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) issue(s0, s0);
@@ -285,8 +299,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   auto tile = [&](auto stage_c, int kt) {
     constexpr int STAGE = decltype(stage_c)::value;
     // tile kt has landed for this wave once only the younger tile's DMAs remain outstanding
-    if (NST == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_wait<NST - 2 < 0 ? 0 : NST - 2, LPW>(nk - 1 - kt);
     __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1) % NST
     if (kt + NST - 1 < nk) issue(kt + NST - 1, (STAGE + NST - 1) % NST);
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
@@ -327,12 +340,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - PER * NL, 0);
     }
   };
+  static_assert(NST >= 2 && NST <= 6, "ring depth");
   for (int kt = 0; kt < nk; kt += NST) {
     tile(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < nk) tile(std::integral_constant<int, 1>{}, kt + 1);
-    if constexpr (NST == 3) {
-      if (kt + 2 < nk) tile(std::integral_constant<int, 2>{}, kt + 2);
-    }
+    if constexpr (NST > 2) { if (kt + 2 < nk) tile(std::integral_constant<int, 2>{}, kt + 2); }
+    if constexpr (NST > 3) { if (kt + 3 < nk) tile(std::integral_constant<int, 3>{}, kt + 3); }
+    if constexpr (NST > 4) { if (kt + 4 < nk) tile(std::integral_constant<int, 4>{}, kt + 4); }
+    if constexpr (NST > 5) { if (kt + 5 < nk) tile(std::integral_constant<int, 5>{}, kt + 5); }
   }
   if (p.vec_epi) {
     __builtin_amdgcn_s_barrier();   // every wave is done reading the K-loop stages; all DMAs were retired above
@@ -396,7 +411,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6 || t->dwconv_rows_per_wave == 8, "v2a_set_tuning: dwconv_rows_per_wave %d",
               t->dwconv_rows_per_wave);
   v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave ? t->dwconv_rows_per_wave : 4;
-  V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 6, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
+  V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 8, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
   V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
   v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,
                                t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,
@@ -508,7 +523,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   // bf16 x bf16: LDS-DMA kernel; tile shape by how many workgroups the problem yields (256 CUs)
   auto ntiles = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
   // wide outputs: 256x256 tile with the phase-interleaved K loop (gemm_8phase.hip) once the problem yields enough tiles
-  V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 7, "v2a_gemm: tile_hint %d", a->tile_hint);
+  V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 9, "v2a_gemm: tile_hint %d", a->tile_hint);
   const bool dense = !a->a_row_offset && !a->out_row_offset && p.vec_epi;
   if (a->tile_hint > 0 && tune.force_tile < 0) {
     if (a->tile_hint == 7) {
@@ -520,6 +535,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
       case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);
       case 1: return dispatch_dma<128, 128, 2, 2>(a, p, s);
       case 2: return dispatch_dma<128, 64, 2, 2>(a, p, s);
+      case 7: return dispatch_dma<64, 128, 2, 2, 6>(a, p, s);
+      case 8: return dispatch_dma<64, 64, 2, 2, 6>(a, p, s);
       default: return dispatch_dma<64, 64, 2, 2>(a, p, s);
     }
   }
@@ -559,6 +576,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);   // 8 waves, 144 KB LDS, 1 workgroup/CU
     case 1: return dispatch_dma<128, 128, 2, 2>(a, p, s);   // 4 waves,  96 KB
     case 2: return dispatch_dma<128, 64, 2, 2>(a, p, s);    // 4 waves,  72 KB, 2 workgroups/CU
+    case 7: return dispatch_dma<64, 128, 2, 2, 6>(a, p, s); // 4 waves, 144 KB: 6-deep ring, 1 workgroup/CU (<= 256 tiles)
+    case 8: return dispatch_dma<64, 64, 2, 2, 6>(a, p, s);  // 4 waves,  96 KB: 6-deep ring, 1 workgroup/CU (<= 256 tiles)
     default: return dispatch_dma<64, 64, 2, 2>(a, p, s);    // 4 waves,  48 KB, 3 workgroups/CU
   }
 }

@@ -233,6 +233,7 @@ class DiTEngine:
         # audio block on side streams -- few fat workgroups that own whole CUs disturb the critical path less than many small
         # ones spread over every CU (+3.5 % end to end); -1 = the library's stand-alone choice
         self.side_tile = 0 if multi_stream else -1
+        self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
@@ -414,6 +415,9 @@ class DiTEngine:
         (8 clips: text feed-forward 325 us on the 256x256 kernel against 556 us on forced 128x256 tiles)."""
         return self.side_tile + 1 if (self.side_tile >= 0 and self.plan["rows"] <= 3200) else 0
 
+    def _main_hint(self):
+        return dict(tile_hint=self.main_tile + 1) if (self.main_tile >= 0 and self.plan["rows"] <= 3200) else {}
+
     def _side_block(self, ly, s, src, dst, nseq, d, parts=(0, 1, 2)):
         """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward.  `parts` selects
         0 = conv + norm, 1 = attention, 2 = norm + feed-forward, so that the caller can interleave the CAPTURE order of the
@@ -594,8 +598,9 @@ class DiTEngine:
             wait(main, eT, eF)
             xn = p["skips"][i] if i < half else xo
             ax, at_, af_ = self._opnd(xc), self._opnd(tc_), self._opnd(fc_)
+            mh = self._main_hint()
             self._mm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D,
-                     epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn))
+                     epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn), **mh)
             if not last:
                 nxt = W.layers[i + 1]
                 hint = self._side_hint() if (multi and not self.cross_on_main) else 0
@@ -624,14 +629,14 @@ class DiTEngine:
                 src = xn
             else:
                 src = p["xS"]
-                self._mm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src, M=rows, N=D, ldo=D)
+                self._mm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src, M=rows, N=D, ldo=D, **mh)
             dst = xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
             L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
             x = dst
             self._norm_ada(x, p["hn_a"], rows, D, i, 0)
-            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0)))
+            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), **mh))
             if not last and self.interleave_capture:
                 for part in (0, 1):
                     with _On(st):
@@ -668,9 +673,9 @@ class DiTEngine:
                 if self.split:
                     L.split_bf16(aout, p["ao_a"], rows=r2, d=inner)
                 self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
-                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1))
+                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh)
             self._norm_ada(x, p["hn_a"], rows, D, i, 2)
-            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2)))
+            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh))
             if not last:
                 if not self.cross_on_main:
                     eA = rec(main)             # x of the next layer is ready
