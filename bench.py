@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--xcd-1x8", action="store_true", help="A/B: round-1 XCD tile order (column strips) instead of the per-shape rectangle grid")
     ap.add_argument("--interleave-capture", type=int, default=-1, help="A/B: 1 = interleave the capture order of audio and side blocks")
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
+    ap.add_argument("--no-fold-norm", action="store_true", help="A/B: separate RMSNorm launches instead of folding them into the neighbouring kernels")
     ap.add_argument("--main-tile", type=int, default=-1, help="A/B: GEMM tile configuration of the audio stream's narrow-output GEMMs (-1 library choice)")
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
@@ -144,6 +145,8 @@ def main():
         model.engine().side_tile = args.side_tile
     if args.main_tile >= 0:
         model.engine().main_tile = args.main_tile
+    if args.no_fold_norm:
+        model.engine().fold_norm = False
     model.engine().cross_on_main = args.cross_on_main
     if args.interleave_capture >= 0:
         model.engine().interleave_capture = bool(args.interleave_capture)

@@ -51,7 +51,7 @@ enum {
   V2A_ERR_LAUNCH = -2  /* hipGetLastError() after launch */
 };
 
-int v2a_abi_version(void);        /* 3 */
+int v2a_abi_version(void);        /* 4 */
 const char* v2a_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -117,6 +117,23 @@ typedef struct v2a_gemm_args {
    * the text / frames streams: their GEMMs run beside the audio stream's, and few fat workgroups that own whole CUs disturb
    * the critical path less than many small ones spread over every CU (+3.5 % end to end, measured). */
   int32_t tile_hint;
+  /* RMSNorm folded into its neighbours (bf16 x bf16, 16-byte aligned epilogue operands, N % 32 == 0):
+   * PRODUCER (RESID / GATE_RESID with out_bf16): with norm_gamma the shadow is out_bf16[m][n] = bf16(out[m][n] * gamma[n]),
+   * gamma = norm_gamma + step[0] * norm_step_stride + (m / rows_per_batch) * norm_batch_stride (+ norm_switch_offset for rows
+   * m >= norm_switch_row: the rows a later GEMM of the block does not touch carry the NEXT norm's gamma), and with norm_ssq
+   * the sums of squares of out[m][32 j .. 32 j + 31] go to norm_ssq[m * ld_norm_ssq + j].
+   * CONSUMER (any epilogue): with row_ssq the accumulator row m is multiplied by
+   * sqrt(row_norm_dim) / max(sqrt(sum_{j < row_ssq_parts} row_ssq[m * ld_row_ssq + j]), 1e-12) before the bias -- F.normalize
+   * of xt RMSNorm / AdaptiveRMSNorm commutes with the product, so norm -> Linear costs no pass of its own.  row_ssq_parts <= 40;
+   * rows of row_ssq are read as whole float4: ld_row_ssq a multiple of 4 and the columns past row_ssq_parts zero. */
+  const float* norm_gamma;
+  int64_t norm_step_stride, norm_batch_stride;
+  int32_t norm_switch_row, norm_switch_offset;
+  float* norm_ssq;
+  int64_t ld_norm_ssq;
+  const float* row_ssq;
+  int64_t ld_row_ssq;
+  int32_t row_ssq_parts, row_norm_dim;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
@@ -131,7 +148,7 @@ typedef struct v2a_tuning {
   int32_t gemm_k_rotation;        /* 1: M bands that share a W panel start their K walk at different K tiles (changes fp32 summation order with M) */
   int32_t gemm_8phase;            /* 256x256 phase-interleaved kernel for wide outputs (N >= 2048): 0 off, 1 on (staggered wave rows), 2 on (lock-step) */
   int32_t gemm_8phase_min_tiles;  /* ... when the problem yields at least this many 256x256 tiles (0 = 400) */
-  int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass, 4, 6 or 8 (0 = default) */
+  int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass, 4 or 6 (0 = default 4) */
   int32_t gemm_xcd_order_1x8;     /* 1: every XCD walks whole column strips of the tile space (the round-1 order) instead of the
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t reserved[2];
@@ -161,6 +178,22 @@ int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, int32_t y_dty
 int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias,
                              int32_t B, int32_t N, int32_t d, int32_t ksize,
                              const int32_t* len, v2a_stream_t stream);
+/* The same with the RMSNorm that follows it folded in (x3:1083,1098,1126): additionally
+ *   out_bf16[b,n,c] = bf16(out[b,n,c] * gamma[c]),  gamma = norm_gamma + step[0] * step_stride + b * batch_stride
+ *   norm_ssq[(b*N + n) * ld_ssq + j] = sum of out[b,n,32j..32j+31]^2
+ * for the GEMM that consumes out_bf16 with row_ssq (v2a_gemm_args).  d % 32 == 0. */
+typedef struct v2a_dwconv_norm {
+  void* out_bf16;
+  int64_t ld_out_bf16;
+  const float* norm_gamma;
+  const int32_t* step;
+  int64_t norm_step_stride, norm_batch_stride;
+  float* norm_ssq;
+  int64_t ld_norm_ssq;
+} v2a_dwconv_norm;
+int v2a_dwconv_silu_residual_norm(const float* x, float* out, const float* wt, const float* bias,
+                                  int32_t B, int32_t N, int32_t d, int32_t ksize,
+                                  const int32_t* len, const v2a_dwconv_norm* norm, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Rotary embedding applied in place to `nheads` consecutive 64-wide heads of every row

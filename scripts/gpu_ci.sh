@@ -71,6 +71,14 @@ for s in "$@"; do
            TAILN=3 run pmcdw$i 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmcdw$i -- python scripts/probes/dwconv_probe.py ${DW_ARGS:-16 782 1024 0} || true
            python scripts/pmc_summary.py /tmp/pmcdw$i gpurun_out/pmcdw${i}_summary.csv || true
          done ;;
+    foldab) for v in "" "--no-fold-norm"; do
+           TAILN=0 run fold_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v
+           echo "--- fold [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/fold_x.log | head -1) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/fold_x.log | head -1)"
+         done ;;
+    foldtab) for v in fold nofold; do
+           f=""; [ $v = nofold ] && f="--no-fold-norm"
+           TAILN=0 run ft_$v 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode --no-configs --no-video2roll --no-vocoder $f
+         done ;;
     maintile) SW="${MAIN_SWEEP:--1 1 2 7}"
          for v in $SW; do
            TAILN=0 run mt_$v 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --main-tile $v

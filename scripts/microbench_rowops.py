@@ -34,8 +34,6 @@ for B, N, d in [(2, 782, 1024), (2, 782, 1280), (2, 782, 512), (16, 782, 1024), 
     out = torch.empty_like(x)
     wt = torch.randn(31, d, device=dev)
     bias = torch.randn(d, device=dev)
-    L.set_tuning(dwconv_rows_per_wave=8)
-    t8 = timeit(lambda: L.dwconv(x, out, wt, bias, B=B, N=N, d=d, ksize=31))
     L.set_tuning(dwconv_rows_per_wave=6)
     t6 = timeit(lambda: L.dwconv(x, out, wt, bias, B=B, N=N, d=d, ksize=31))
     L.set_tuning()
@@ -45,4 +43,4 @@ for B, N, d in [(2, 782, 1024), (2, 782, 1280), (2, 782, 512), (16, 782, 1024), 
     tn = timeit(lambda: L.rmsnorm(x, y, rows=B * N, d=d, gamma=g))
     mb = B * N * d * 8 / 1e6
     mbn = B * N * d * 6 / 1e6
-    print(f"B={B:2d} N={N:4d} d={d:4d}: dwconv TN4 {t:7.2f} us ({mb / t * 1e3:7.1f} GB/s) TN6 {t6:7.2f} us TN8 {t8:7.2f} us   rmsnorm {tn:6.2f} us ({mbn / tn * 1e3:7.1f} GB/s)", flush=True)
+    print(f"B={B:2d} N={N:4d} d={d:4d}: dwconv TN4 {t:7.2f} us ({mb / t * 1e3:7.1f} GB/s) TN6 {t6:7.2f} us rmsnorm {tn:6.2f} us ({mbn / tn * 1e3:7.1f} GB/s)", flush=True)

@@ -66,10 +66,10 @@ def test_adaptive_rmsnorm_golden(L, small, golden):
 
 
 # -------------------------------------------------------------------------------- dwconv
-@pytest.mark.parametrize("tn", [4, 6, 8])
+@pytest.mark.parametrize("tn", [4, 6])
 @pytest.mark.parametrize("N,d,lens", [(44, 128, [44, 30]), (782, 512, None), (7, 64, [7, 3]), (100, 1280, [100, 33]), (782, 1024, [782, 1])])
 def test_dwconv(L, N, d, lens, tn):
-    """All position-tile sizes of the kernel (4 / 6 / 8 outputs per wave pass); edge tiles, masked tails, a 1-frame clip."""
+    """All position-tile sizes of the kernel (4 / 6 outputs per wave pass); edge tiles, masked tails, a 1-frame clip."""
     B = 2
     x = torch.randn(B, N, d, generator=_g(N))
     w = torch.randn(d, 1, 31, generator=_g(N + 1)) / math.sqrt(31)
@@ -652,3 +652,131 @@ def test_gemm_deep_ring_k_tails(L, hint, K):
     acat = torch.cat([a.float().cpu() for a in segs], 1).double()
     exact = resid.double().cpu() + gate.double().cpu() * (acat @ w.float().double().cpu().t() + bias.double().cpu())
     torch.testing.assert_close(got.cpu().double(), exact, atol=5e-4, rtol=1e-4)
+
+
+# -------------------------------------------------------------------------------- RMSNorm folded into its neighbours
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 7])
+@pytest.mark.parametrize("epi", ["resid", "gate_resid"])
+def test_gemm_folded_norm_producer(L, hint, epi):
+    """RESID / GATE_RESID with norm_gamma + norm_ssq: the bf16 shadow is bf16(out * gamma) with the step-indexed gamma row
+    (and the switched row for m >= norm_switch_row), the sums of squares of out per 32 columns land in norm_ssq -- for every
+    tile shape, with ragged M / N edges."""
+    M, N, K, rpb = 333, 416, 192, 111
+    g = _g(hint * 7 + len(epi))
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(DEV)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    gam = (1.0 + 0.3 * torch.randn(3, 2, N, generator=g)).to(DEV)          # [step][slot][N]
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    out = torch.empty(M, N, device=DEV)
+    sh = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    ssq = torch.full((M, N // 32), -1.0, device=DEV)
+    kw = dict(M=M, N=N, compute=L.BF16, bias=bias, resid=resid, step=step, rows_per_batch=rpb, tile_hint=hint, out_bf16=sh,
+              norm_gamma=gam[0, 0], norm_step_stride=gam.stride(0), norm_switch_row=2 * rpb, norm_switch_offset=N, norm_ssq=ssq)
+    if epi == "gate_resid":
+        gate = torch.rand(3, N, generator=g).to(DEV)
+        kw.update(epilogue=L.EPI_GATE_RESID, gate=gate, gate_step_stride=N)
+    else:
+        kw.update(epilogue=L.EPI_RESID)
+    L.gemm([(a, K, K)], w, out, **kw)
+    plain = torch.empty(M, N, device=DEV)
+    kw2 = {k: v for k, v in kw.items() if not k.startswith("norm_") and k != "out_bf16"}
+    L.gemm([(a, K, K)], w, plain, **kw2)
+    assert torch.equal(out, plain)                                          # the fp32 result is untouched by the fold
+    grow = torch.where((torch.arange(M, device=DEV) >= 2 * rpb)[:, None], gam[2, 1][None], gam[2, 0][None])
+    assert torch.equal(sh, (out * grow).bfloat16())
+    ref = (out.double() ** 2).reshape(M, N // 32, 32).sum(-1)
+    torch.testing.assert_close(ssq.double(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("hint", [0, 1, 4, 7])
+@pytest.mark.parametrize("epi", ["store_bf16", "store_f32", "geglu", "store_rope"])
+def test_gemm_folded_norm_consumer(L, hint, epi):
+    """row_ssq: accumulator row m is scaled by sqrt(d) / max(sqrt(sum of its partial sums), 1e-12) before bias / GELU / RoPE."""
+    M, N, K, d = 300, 512, 256, 192                                         # 6 partial sums: the row is padded to 8 with zeros
+    g = _g(hint + 31 * len(epi))
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(DEV)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    ssq = torch.zeros(M, 8)
+    ssq[:, :d // 32] = torch.rand(M, d // 32, generator=g) * 40 + 1
+    ssq = ssq.to(DEV)
+    ssq[5] = 0.0                                                            # an all-zero row: eps clamp, 0 * huge = 0, no NaN
+    a[5] = 0
+    rstd = (math.sqrt(d) / ssq.double().sum(-1).sqrt().clamp_min(1e-12)).cpu()
+    acc = a.float().double().cpu() @ w.float().double().cpu().t()
+    kw = dict(M=M, N=N, compute=L.BF16, bias=bias, tile_hint=hint, row_ssq=ssq, row_norm_dim=d)
+    if epi == "geglu":
+        out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV)
+        L.gemm([(a, K, K)], w, out, epilogue=L.EPI_GEGLU, ldo=N // 2, **kw)
+        z = (acc * rstd[:, None] + bias.double().cpu()).reshape(M, N // 32, 2, 16)
+        ref = (z[:, :, 0] * torch.nn.functional.gelu(z[:, :, 1])).reshape(M, N // 2)
+        ref[5] = (bias.double().cpu().reshape(N // 32, 2, 16)[:, 0] * torch.nn.functional.gelu(bias.double().cpu().reshape(N // 32, 2, 16)[:, 1])).reshape(-1)
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-2, atol=2e-2)
+        return
+    if epi == "store_rope":
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        L.gemm([(a, K, K)], w, out, rope_table=_rope_table(M).to(DEV), rope_cols=128, rope_pos_offset=0, rows_per_batch=M, **kw)
+        ref = (acc * rstd[:, None] + bias.double().cpu()).float()
+        ref[5] = bias.cpu()
+        q = ref[:, :128].reshape(1, M, 2, 64).permute(0, 2, 1, 3)
+        ref[:, :128] = O.apply_rope(q, O.rotary_freqs(M, 64, "interleaved"), "interleaved").permute(0, 2, 1, 3).reshape(M, 128)
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-2, atol=3e-2)
+        return
+    out = torch.empty(M, N, dtype=torch.bfloat16 if epi == "store_bf16" else torch.float32, device=DEV)
+    L.gemm([(a, K, K)], w, out, **kw)
+    ref = acc * rstd[:, None] + bias.double().cpu()
+    ref[5] = bias.double().cpu()                                            # 0 * (sqrt(d) / 1e-12) = 0
+    tol = dict(rtol=1e-2, atol=2e-2) if epi == "store_bf16" else dict(rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(out.cpu().double(), ref, **tol)
+
+
+@pytest.mark.parametrize("N,d,lens", [(44, 128, [44, 30]), (782, 512, None), (100, 1280, [100, 33]), (782, 1024, [782, 1])])
+def test_dwconv_folded_norm(L, N, d, lens):
+    """v2a_dwconv_silu_residual_norm: the fp32 result equals the plain kernel's bit for bit; the bf16 copy is bf16(out * gamma)
+    with the step- and batch-indexed gamma row; the sums of squares per 32 channels match."""
+    B = 2
+    x = torch.randn(B, N, d, generator=_g(N)).to(DEV)
+    w = (torch.randn(31, d, generator=_g(N + 1)) / math.sqrt(31)).to(DEV)
+    bias = (0.1 * torch.randn(d, generator=_g(N + 2))).to(DEV)
+    ld = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=DEV)
+    gam = (1.0 + 0.3 * torch.randn(3, B, d, generator=_g(N + 3))).to(DEV)
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)
+    plain, out = torch.empty(B, N, d, device=DEV), torch.empty(B, N, d, device=DEV)
+    hn = torch.zeros(B * N, d, dtype=torch.bfloat16, device=DEV)
+    ssq = torch.full((B * N, d // 32), -1.0, device=DEV)
+    L.dwconv(x, plain, w, bias, B=B, N=N, d=d, ksize=31, lens=ld)
+    L.dwconv(x, out, w, bias, B=B, N=N, d=d, ksize=31, lens=ld,
+             norm=dict(out_bf16=hn, gamma=gam[0, 0], ssq=ssq, step=step, step_stride=gam.stride(0), batch_stride=gam.stride(1)))
+    assert torch.equal(out, plain)
+    assert torch.equal(hn.reshape(B, N, d), (out * gam[1][:, None, :]).bfloat16())
+    ref = (out.double() ** 2).reshape(B * N, d // 32, 32).sum(-1)
+    torch.testing.assert_close(ssq.double(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_folded_norm_chain_equals_norm_then_linear(L):
+    """conv -> RMSNorm -> Linear with the norm folded (gamma on the conv's bf16 copy, 1 / rms in the GEMM epilogue) against the
+    three separate kernels: same result up to the bf16 rounding of the operand (the scale moves across the rounding)."""
+    B, N, d, Nout = 2, 782, 1024, 384
+    x = torch.randn(B, N, d, generator=_g(1)).to(DEV)
+    w = (torch.randn(31, d, generator=_g(2)) / math.sqrt(31)).to(DEV)
+    bias = (0.1 * torch.randn(d, generator=_g(3))).to(DEV)
+    gam = (1.0 + 0.2 * torch.randn(d, generator=_g(4))).to(DEV)
+    W = (torch.randn(Nout, d, generator=_g(5)) / math.sqrt(d)).bfloat16().to(DEV)
+    b2 = (0.1 * torch.randn(Nout, generator=_g(6))).to(DEV)
+    y = torch.empty(B, N, d, device=DEV)
+    hn = torch.empty(B * N, d, dtype=torch.bfloat16, device=DEV)
+    L.dwconv(x, y, w, bias, B=B, N=N, d=d, ksize=31)
+    L.rmsnorm(y, hn, rows=B * N, d=d, gamma=gam)
+    ref = torch.empty(B * N, Nout, device=DEV)
+    L.gemm([(hn, d, d)], W, ref, M=B * N, N=Nout, compute=L.BF16, bias=b2)
+    hn2 = torch.empty(B * N, d, dtype=torch.bfloat16, device=DEV)
+    ssq = torch.empty(B * N, d // 32, device=DEV)
+    L.dwconv(x, y, w, bias, B=B, N=N, d=d, ksize=31, norm=dict(out_bf16=hn2, gamma=gam, ssq=ssq))
+    got = torch.empty(B * N, Nout, device=DEV)
+    L.gemm([(hn2, d, d)], W, got, M=B * N, N=Nout, compute=L.BF16, bias=b2, row_ssq=ssq, row_norm_dim=d)
+    exact = torch.nn.functional.linear(torch.nn.functional.normalize(y.reshape(B * N, d), dim=-1) * math.sqrt(d) * gam, W.float(), b2)
+    e_ref, e_got = float((ref - exact).abs().max()), float((got - exact).abs().max())
+    print(f"norm -> linear vs fp32: separate kernels {e_ref:.3e}, folded {e_got:.3e}")
+    assert e_got < 1.5 * e_ref + 1e-3

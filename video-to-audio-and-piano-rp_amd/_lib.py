@@ -41,7 +41,17 @@ class GemmArgs(C.Structure):
         ("rope_table", C.c_void_p), ("rope_cols", C.c_int32), ("rope_pos_offset", C.c_int32), ("relu", C.c_int32),
         ("a_row_offset", C.c_void_p), ("a_ktile_offset", C.c_void_p), ("out_row_offset", C.c_void_p),
         ("tile_hint", C.c_int32),
+        ("norm_gamma", C.c_void_p), ("norm_step_stride", C.c_int64), ("norm_batch_stride", C.c_int64),
+        ("norm_switch_row", C.c_int32), ("norm_switch_offset", C.c_int32),
+        ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64),
+        ("row_ssq", C.c_void_p), ("ld_row_ssq", C.c_int64), ("row_ssq_parts", C.c_int32), ("row_norm_dim", C.c_int32),
     ]
+
+
+class DwconvNorm(C.Structure):
+    """Mirror of `v2a_dwconv_norm`: the RMSNorm after the depthwise convolution, folded into it."""
+    _fields_ = [("out_bf16", C.c_void_p), ("ld_out_bf16", C.c_int64), ("norm_gamma", C.c_void_p), ("step", C.c_void_p),
+                ("norm_step_stride", C.c_int64), ("norm_batch_stride", C.c_int64), ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64)]
 
 
 class Tuning(C.Structure):
@@ -72,7 +82,7 @@ class RollHeadArgs(C.Structure):
 
 
 EXPORTS = [
-    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual",
+    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual", "v2a_dwconv_silu_residual_norm",
     "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16", "v2a_split_bf16",
     "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
@@ -94,7 +104,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-ABI_VERSION = 3          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
+ABI_VERSION = 4          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
 
 
 def _declare(lib):
@@ -107,6 +117,7 @@ def _declare(lib):
     lib.v2a_attention.argtypes = [C.POINTER(AttnArgs), vp]
     lib.v2a_rmsnorm.argtypes = [vp, i64, vp, i64, i32, i64, i32, vp, vp, i64, i64, i32, vp]
     lib.v2a_dwconv_silu_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.v2a_dwconv_silu_residual_norm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(DwconvNorm), vp]
     lib.v2a_rope_inplace.argtypes = [vp, i32, i64, i64, i32, i32, i32, vp, i32, vp]
     lib.v2a_linear_small.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, vp]
     lib.v2a_fill_registers.argtypes = [vp, i64, vp, i32, i32, i32, vp]
@@ -268,8 +279,12 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
-         a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0):
-    """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype."""
+         a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0,
+         norm_gamma=None, norm_step_stride=0, norm_batch_stride=0, norm_switch_row=0, norm_switch_offset=0, norm_ssq=None,
+         row_ssq=None, row_norm_dim=0):
+    """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype.
+    Folded RMSNorm (v2a_gemm_args): producer -- norm_gamma (+ strides / switch) scales the out_bf16 shadow, norm_ssq (rows, N/32)
+    receives the sums of squares; consumer -- row_ssq (rows, parts) of its A rows and row_norm_dim = their width."""
     g = GemmArgs()
     for i, (t, lda, k) in enumerate(a_segs):
         g.a[i] = t.data_ptr()
@@ -300,6 +315,15 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.relu = 1 if relu else 0
     g.a_row_offset, g.a_ktile_offset, g.out_row_offset = _p(a_row_offset), _p(a_ktile_offset), _p(out_row_offset)
     g.tile_hint = tile_hint if compute == BF16 and g.a_dtype == BF16 and epilogue != EPI_SIGMOID else 0
+    g.norm_gamma = _p(norm_gamma)
+    g.norm_step_stride, g.norm_batch_stride = norm_step_stride, norm_batch_stride
+    g.norm_switch_row, g.norm_switch_offset = norm_switch_row, norm_switch_offset
+    g.norm_ssq = _p(norm_ssq)
+    g.ld_norm_ssq = norm_ssq.stride(-2) if norm_ssq is not None else 0
+    g.row_ssq = _p(row_ssq)
+    g.ld_row_ssq = row_ssq.stride(-2) if row_ssq is not None else 0
+    g.row_ssq_parts = row_norm_dim // 32 if row_ssq is not None else 0
+    g.row_norm_dim = row_norm_dim
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
@@ -325,10 +349,21 @@ def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch
                                       stream_ptr()))
 
 
-def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None):
-    _launch("dwconv", 2.0 * B * N * d * ksize, B * N * d * 8,
-            lambda: lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
-                                                   B, N, d, ksize, _p(lens), stream_ptr()))
+def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm=None):
+    """norm = dict(out_bf16, gamma, ssq, step=None, step_stride=0, batch_stride=0): the RMSNorm after the conv folded in."""
+    if norm is None:
+        _launch("dwconv", 2.0 * B * N * d * ksize, B * N * d * 8,
+                lambda: lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                       B, N, d, ksize, _p(lens), stream_ptr()))
+        return
+    n = DwconvNorm()
+    n.out_bf16, n.ld_out_bf16 = norm["out_bf16"].data_ptr(), norm.get("ld_out_bf16", d)
+    n.norm_gamma, n.step = norm["gamma"].data_ptr(), _p(norm.get("step"))
+    n.norm_step_stride, n.norm_batch_stride = norm.get("step_stride", 0), norm.get("batch_stride", 0)
+    n.norm_ssq, n.ld_norm_ssq = norm["ssq"].data_ptr(), norm["ssq"].stride(-2)
+    _launch("dwconv+norm", 2.0 * B * N * d * ksize, B * N * d * 10,
+            lambda: lib().v2a_dwconv_silu_residual_norm(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                        B, N, d, ksize, _p(lens), C.byref(n), stream_ptr()))
 
 
 def rope(qk, *, rows, row_stride, nheads, rows_per_batch, pos_offset, table, layout):

@@ -288,6 +288,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   constexpr bool PF = BM * BN <= 128 * 256 && !(EPI == V2A_EPI_GATE_RESID && BM * BN == 128 * 256);
   EpiPrefetch<EPI, TM, WN, PF> pf;
   if (p.vec_epi) pf.load(p, m0 + wm * WM, n0 + wn * WN, lane);
+  // folded RMSNorm (consumer): the row's partial sums are requested ahead of the first operand DMA ...
+  static_assert(BM <= 64 * NW, "one thread per tile row");
+  float* rs_lds = reinterpret_cast<float*>(smem_raw + NST * STAGE_BYTES);
+  const bool scaled = p.rssq != nullptr && p.vec_epi;
+  RowScaleLoad rsl;
+  if (scaled && tid < BM) rowscale_load(p, m0 + tid, rsl);
   const int nk = p.K / 64;
   // ring of NST stages, NST - 1 K tiles in flight while one is computed (3 by default; 2: the 256x256 tile, whose 64 KB
   // stages leave room for only two; 6: the small tiles of a one-clip launch, which has at most one workgroup per CU and is
@@ -295,6 +301,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) issue(s0, s0);
+  // ... and turned into the row's scale behind them (visible to every wave after the K loop's barriers)
+  if (scaled && tid < BM) rs_lds[tid] = rowscale_finish(p, rsl);
   // one K tile; STAGE is a compile-time ring position so every LDS address is base + immediate
   auto tile = [&](auto stage_c, int kt) {
     constexpr int STAGE = decltype(stage_c)::value;
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     __builtin_amdgcn_s_barrier();   // every wave is done reading the K-loop stages; all DMAs were retired above
     static_assert(NW * 16 * (WN + 4) * 4 <= NST * STAGE_BYTES, "epilogue slabs must fit in the ring memory");
     float* tile = reinterpret_cast<float*>(smem_raw) + wave * (16 * (WN + 4));
-    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN, PF>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane, pf);
+    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN, PF>(p, acc, tile, m0 + wm * WM, n0 + wn * WN, lane, pf, scaled ? rs_lds + wm * WM : nullptr);
   } else {
     gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, lr, lq);
   }
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 
 template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST>
 int launch_dma(const GemmParams& p, hipStream_t s) {
-  constexpr size_t smem = NST * (size_t)(BM + BN) * 128;
+  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 + BM * 4;    // the ring + one row scale per tile row (folded RMSNorm)
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
@@ -408,7 +416,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
     v2a_detail::g_dwconv_rows_per_wave = 4;
     return V2A_OK;
   }
-  V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6 || t->dwconv_rows_per_wave == 8, "v2a_set_tuning: dwconv_rows_per_wave %d",
+  V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6, "v2a_set_tuning: dwconv_rows_per_wave %d",
               t->dwconv_rows_per_wave);
   v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave ? t->dwconv_rows_per_wave : 4;
   V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 8, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
@@ -504,6 +512,32 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
                 "v2a_gemm: row/K-tile offset tables need one bf16 segment, bf16 compute, STORE/RESID and 16-byte aligned rows");
   }
   V2A_REQUIRE(!a->relu || a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: relu with GEGLU");
+  p.ngam = a->norm_gamma;
+  p.ngss = a->norm_step_stride;
+  p.ngbs = a->norm_batch_stride;
+  p.nsw_row = a->norm_switch_row > 0 ? a->norm_switch_row : INT32_MAX;
+  p.nsw_off = a->norm_switch_offset;
+  p.ssq = a->norm_ssq;
+  p.ssq_ld = a->ld_norm_ssq;
+  p.rssq = a->row_ssq;
+  p.rssq_ld = a->ld_row_ssq;
+  p.rssq_parts = a->row_ssq_parts;
+  p.rnorm = sqrtf((float)a->row_norm_dim);
+  if (a->norm_gamma || a->norm_ssq || a->row_ssq) {
+    V2A_REQUIRE(a->compute_dtype == V2A_BF16 && a->a_dtype == V2A_BF16 && p.vec_epi && a->epilogue != V2A_EPI_SIGMOID && !a->out_row_offset,
+                "v2a_gemm: a folded RMSNorm needs bf16 x bf16 operands, dense rows and 16-byte aligned epilogue operands");
+    if (a->norm_gamma || a->norm_ssq)
+      V2A_REQUIRE(a->out_bf16 && (a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID) && a->N % 32 == 0 &&
+                      (!a->norm_gamma || (((uintptr_t)a->norm_gamma & 15) == 0 && a->norm_step_stride % 4 == 0 && a->norm_batch_stride % 4 == 0 &&
+                                          a->norm_switch_offset % 4 == 0)) &&
+                      (!a->norm_ssq || a->ld_norm_ssq >= a->N / 32),
+                  "v2a_gemm: norm_gamma / norm_ssq go with RESID / GATE_RESID, an out_bf16 shadow and N %% 32 == 0 (N=%d)", a->N);
+    if (a->row_ssq)
+      V2A_REQUIRE(a->row_ssq_parts > 0 && a->row_ssq_parts <= 40 && a->row_norm_dim > 0 && a->ld_row_ssq >= (a->row_ssq_parts + 3) / 4 * 4 &&
+                      a->ld_row_ssq % 4 == 0 && ((uintptr_t)a->row_ssq & 15) == 0,
+                  "v2a_gemm: row_ssq needs row_ssq_parts <= 40 (%d), row_norm_dim (%d) and rows of whole float4 (zero padded)", a->row_ssq_parts,
+                  a->row_norm_dim);
+  }
   p.rope = a->rope_table;
   p.rope_cols = a->rope_cols;
   p.rope_pos_off = a->rope_pos_offset;

@@ -140,6 +140,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
+  // folded RMSNorm (consumer): request the tile rows' partial sums ahead of the operand DMAs (gemm_common.h, rowscale_load)
+  float* rs_lds = reinterpret_cast<float*>(smem_raw + 2 * BUF);
+  const bool scaled = p.rssq != nullptr && p.vec_epi;
+  RowScaleLoad rsl;
+  if (scaled && tid < 256) rowscale_load(p, m0 + tid, rsl);
   // ---- prologue: K tile 0 whole, plus the three halves of K tile 1 the steady state would have issued already
   stage_a(0, 0, 0);
   stage_b(0, 0, 0);
@@ -149,8 +154,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     stage_a(0, 1, 1);
     stage_b(0, 1, 1);
     stage_b(1, 1, 1);
+    if (scaled && tid < 256) rs_lds[tid] = rowscale_finish(p, rsl);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
+    if (scaled && tid < 256) rs_lds[tid] = rowscale_finish(p, rsl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     static_assert(8 * 16 * (WN + 4) * 4 <= 2 * BUF, "epilogue slabs must fit in the ring memory");
     float* tile = reinterpret_cast<float*>(smem_raw) + wave * (16 * (WN + 4));
     EpiPrefetch<EPI, TM, WN, false> pf;
-    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN, false>(p, acc, tile, m0 + wr * WM, n0 + wc * WN, lane, pf);
+    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN, false>(p, acc, tile, m0 + wr * WM, n0 + wc * WN, lane, pf, scaled ? rs_lds + wr * WM : nullptr);
   } else {
     gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wr, wc, lr, lq);
   }
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
 
 template <int EPI, typename OutT>
 int launch_8ph(const GemmParams& p, hipStream_t s) {
-  constexpr size_t smem = 2 * 4 * 128 * 128;
+  constexpr size_t smem = 2 * 4 * 128 * 128 + 256 * 4;     // two buffers of four half tiles + one row scale per tile row (folded RMSNorm)
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool stagger = v2a_detail::g_gemm_tuning.use_8phase != 2;
   if (stagger) {

@@ -37,6 +37,17 @@ struct GemmParams {
   const int32_t* a_koff;
   const int32_t* o_rowoff;
   int32_t krot;     // start each M band's K walk at a different K tile (see the kernel)
+  // RMSNorm folded into its neighbours (v2a_gemm_args: norm_gamma .. row_norm_dim).  Producer: out2 = bf16(out * gamma),
+  // ssq[m][n / 32] = sum of squares of 32 output columns.  Consumer: acc row m is scaled by rnorm / max(sqrt(sum_j rssq[m][j]), eps)
+  const float* ngam;
+  int64_t ngss, ngbs;
+  int32_t nsw_row, nsw_off;
+  float* ssq;
+  int64_t ssq_ld;
+  const float* rssq;
+  int64_t rssq_ld;
+  int32_t rssq_parts;
+  float rnorm;
   int32_t xcd_gm, xcd_gn;   // the 8 XCDs as a gm x gn grid over the tile space (gm * gn == 8): see tile_of_block
 };
 
@@ -174,7 +185,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       const int m = m0 + wm * WM + i * 16 + lq * 4 + jj;
       if (m >= p.M) continue;
       const float* gvec = nullptr;
-      if constexpr (EPI == V2A_EPI_GATE_RESID) gvec = step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb);
+      if constexpr (EPI == V2A_EPI_GATE_RESID) gvec = step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0);
       if constexpr (EPI == V2A_EPI_GEGLU) {
 #pragma unroll
         for (int j = 0; j < TN; j += 2) {
@@ -272,16 +283,41 @@ template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
             int64_t off = (int64_t)m * ldr;
             if constexpr (SCAT) { if (orow) off = ro[i][q]; }
             rs[i][q] = *reinterpret_cast<const f32x4*>(resid + off);
-            if constexpr (GATE) gt[i][q] = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+            if constexpr (GATE) gt[i][q] = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0) + n);
           }
         }
     }
   }
 };
 
+// Folded RMSNorm, consumer side: 1 / rms of A row m (F.normalize: x / max(||x||, 1e-12), times sqrt(d)) from the sums of squares
+// the producer of that row left per 32 columns.  One thread per tile row requests the row's partial sums when the kernel starts
+// (before the first operand DMA, so waiting for them drains nothing), adds them up in a fixed order -- the scale does not depend
+// on the tile shape -- and leaves the scale in LDS behind the ring for the epilogue.
+constexpr int kRowSsqMax = 40;                // partial sums per row: d <= 1280
+struct RowScaleLoad {
+  f32x4 v[kRowSsqMax / 4];
+};
+__device__ __forceinline__ void rowscale_load(const GemmParams& p, int m, RowScaleLoad& r) {
+  m = m < p.M ? m : p.M - 1;
+  const float* q = p.rssq + (int64_t)m * p.rssq_ld;
+#pragma unroll
+  for (int k = 0; k < kRowSsqMax / 4; ++k) {
+    r.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (4 * k < p.rssq_parts) r.v[k] = *reinterpret_cast<const f32x4*>(q + 4 * k);
+  }
+}
+__device__ __forceinline__ float rowscale_finish(const GemmParams& p, const RowScaleLoad& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kRowSsqMax / 4; ++k) s += (r.v[k][0] + r.v[k][1]) + (r.v[k][2] + r.v[k][3]);
+  return p.rnorm / fmaxf(sqrtf(s), 1e-12f);
+}
+
 template <int EPI, typename OutT, int TM, int TN, int WM, int WN, bool PF>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[TM][TN], float* tile /* wave-private, 16 x (WN+4) floats */,
-                                                  int m_base, int n_base, int lane, const EpiPrefetch<EPI, TM, WN, PF>& pf) {
+                                                  int m_base, int n_base, int lane, const EpiPrefetch<EPI, TM, WN, PF>& pf,
+                                                  const float* rs_row = nullptr /* LDS: row scales of this wave's rows, or null */) {
   constexpr int LD = WN + 4;                   // 16-B aligned rows, <= 2-way write conflicts
   const int lr = lane & 15, lq = lane >> 4;
   OutT* out = reinterpret_cast<OutT*>(p.out);
@@ -292,6 +328,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
   const int64_t ldo = p.ldo, ldr = p.ldr, ldo2 = p.ldo2;
   bf16_t* out2 = p.out2;
   const float* resid = p.resid;
+  // folded RMSNorm, consumer side: one scale per row this lane touches, all requested before the first slab is staged
+  constexpr int LPRX = (EPI == V2A_EPI_GEGLU ? WN / 2 : WN) / 4;   // lanes per row of the store loops below
+  constexpr int RPSX = 16 / (64 / LPRX);                           // rows per lane per slab
+  // folded RMSNorm, producer side: the gamma pieces of this lane's four columns, loaded once (they depend on the row only through
+  // the switch row, or through the batch when every clip has its own time -- then they are fetched per row below)
+  f32x4 gmA = {1.f, 1.f, 1.f, 1.f}, gmB = gmA;
+  if constexpr ((EPI == V2A_EPI_RESID || EPI == V2A_EPI_GATE_RESID) && sizeof(OutT) == 4) {
+    const int nn = n_base + (lane % (WN / 4)) * 4;
+    if (out2 && p.ngam && p.ngbs == 0 && nn + 3 < p.N) {
+      const float* gb = step_vec(p.ngam, p.step, p.ngss, 0, 0) + nn;
+      gmA = *reinterpret_cast<const f32x4*>(gb);
+      gmB = *reinterpret_cast<const f32x4*>(gb + p.nsw_off);
+    }
+  }
+  float rsc[TM][RPSX];
+  const bool scaled = rs_row != nullptr;                           // wave-uniform
+  if (scaled) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < RPSX; ++q) rsc[i][q] = rs_row[i * 16 + lane / LPRX + q * (64 / LPRX)];
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     // one 16-row slab of the wave tile at a time: the staging area of a workgroup is a few KB of one ring stage
@@ -313,11 +371,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         bg = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
       }
 #pragma unroll
-      for (int r = r0; r < 16; r += RPI) {
+      for (int q = 0; q < 16 / RPI; ++q) {
+        const int r = r0 + q * RPI;
         const int m = m_base + i * 16 + r;
         if (m >= p.M || n >= p.N) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
+        f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc);
+        f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16);
+        if (scaled) {
+          v *= rsc[i][q];
+          g *= rsc[i][q];
+        }
         OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
         if constexpr (sizeof(OutT) == 2) {
           bf16x4 o;
@@ -354,6 +417,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
           }
         }
         f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + c4);
+        if (scaled) v *= rsc[i][q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bv[e];
         if constexpr (EPI == V2A_EPI_SIGMOID) {
@@ -380,7 +444,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
             if constexpr (EPI == V2A_EPI_GATE_RESID) gt = pf.gt[i][q];
           } else {
             rs = *reinterpret_cast<const f32x4*>(resid + o_res + n);
-            if constexpr (EPI == V2A_EPI_GATE_RESID) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, m / p.rpb) + n);
+            if constexpr (EPI == V2A_EPI_GATE_RESID) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0) + n);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
@@ -397,10 +461,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         } else {
           *reinterpret_cast<f32x4*>(out + o_out + n) = v;
           if (out2) {
+            // folded RMSNorm, producer side: the shadow carries the norm's gamma (the consumer applies 1 / rms per row) and
+            // the row's sum of squares is left per 32 columns (8 lanes x 4 columns: a butterfly inside the lane octet)
+            f32x4 gm = m >= p.nsw_row ? gmB : gmA;
+            if (p.ngam && p.ngbs) gm = *reinterpret_cast<const f32x4*>(step_vec(p.ngam, p.step, p.ngss, p.ngbs, m / p.rpb) + (m >= p.nsw_row ? p.nsw_off : 0) + n);
             bf16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(v[e] * gm[e]);
             *reinterpret_cast<bf16x4*>(out2 + o_out2 + n) = o;
+            if (p.ssq) {
+              const float ss = octet_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+              if ((lane & 7) == 0) p.ssq[(int64_t)m * p.ssq_ld + (n >> 5)] = ss;
+            }
           }
         }
       }

@@ -8,7 +8,7 @@ namespace v2a_detail { extern int g_dwconv_rows_per_wave; }
 
 thread_local char v2a_err_buf[512] = {0};
 
-extern "C" int v2a_abi_version(void) { return 3; }
+extern "C" int v2a_abi_version(void) { return 4; }
 extern "C" const char* v2a_last_error(void) { return v2a_err_buf; }
 
 namespace {
@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // all 31 taps in registers: 396 VGPRs, one wave per SIMD, and at 8 clips per GPU it ran VALU-bound at 1.4 TB/s with
 // nothing to overlap a block's load phase with.)  Algorithmic traffic: 4*d B in + 4*d B out per position.
 // ------------------------------------------------------------------------------------------
-template <int KS, int TN>
+template <int KS, int TN, bool NORM>
 __global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                         const float* __restrict__ wt, const float* __restrict__ bias,
-                                                        int B, int N, int d, const int32_t* len, int P, int walkers) {
+                                                        int B, int N, int d, const int32_t* len, int P, int walkers, v2a_dwconv_norm nrm) {
   constexpr int HALF = KS / 2;
   constexpr int NG = ((TN + KS - 1 + TN - 1) / TN + 2) / 3 * 3;   // row groups of TN rows, a multiple of the 3 load buffers
   constexpr int TAPS = NG * TN;                          // tap rows in LDS: the k real taps, zero rows for the window slots past them
@@ -206,6 +206,8 @@ __global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const floa
       f32x4 center[TN];
 #pragma unroll
       for (int t = 0; t < TN; ++t) center[t] = *reinterpret_cast<const f32x4*>(xrow0 + min(n0 + t, N - 1) * stride + loff);
+      f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (NORM) gm = *reinterpret_cast<const f32x4*>(step_vec(nrm.norm_gamma, nrm.step, nrm.norm_step_stride, nrm.norm_batch_stride, b) + 4 * cc);
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         const int n = n0 + t;
@@ -217,6 +219,17 @@ __global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const floa
             for (int j = 0; j < 4; ++j) o[j] += acc[t][j] * __builtin_amdgcn_rcpf(1.0f + __expf(-acc[t][j]));
           }
           *reinterpret_cast<f32x4*>(orow0 + n * stride + loff) = o;
+          if constexpr (NORM) {
+            // the RMSNorm after the conv, folded: the bf16 operand of the next GEMM carries gamma, the row's sum of squares
+            // is left per 32 channels (a lane octet) for that GEMM's epilogue
+            const int64_t row = (int64_t)b * N + n;
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)(o[j] * gm[j]);
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(nrm.out_bf16) + row * nrm.ld_out_bf16 + 4 * cc) = ob;
+            const float ss = octet_sum(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+            if ((lane & 7) == 0) nrm.norm_ssq[row * nrm.ld_norm_ssq + (cc >> 3)] = ss;
+          }
         }
       }
     }
@@ -512,13 +525,18 @@ extern "C" int v2a_rmsnorm(const float* x, int64_t ldx, void* y, int64_t ldy, in
   return v2a_check_launch("v2a_rmsnorm");
 }
 
-extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias, int32_t B,
-                                        int32_t N, int32_t d, int32_t ksize, const int32_t* len, v2a_stream_t stream) {
+static int dwconv_launch(const float* x, float* out, const float* wt, const float* bias, int32_t B, int32_t N, int32_t d, int32_t ksize,
+                         const int32_t* len, const v2a_dwconv_norm* norm, v2a_stream_t stream) {
   V2A_REQUIRE(x && out && wt && bias, "v2a_dwconv: null pointer");
   V2A_REQUIRE(x != out, "v2a_dwconv: out must not alias x (halo reads)");
   V2A_REQUIRE(ksize == 31, "v2a_dwconv: kernel_size %d (only 31 is built, x3:726)", ksize);
   V2A_REQUIRE(d % 4 == 0 && B > 0 && N > 0, "v2a_dwconv: B=%d N=%d d=%d", B, N, d);
-  const int TN = v2a_detail::g_dwconv_rows_per_wave;
+  if (norm)
+    V2A_REQUIRE(norm->out_bf16 && norm->norm_gamma && norm->norm_ssq && d % 32 == 0 && norm->ld_out_bf16 % 4 == 0 && norm->ld_out_bf16 >= d &&
+                    ((uintptr_t)norm->out_bf16 & 7) == 0 && ((uintptr_t)norm->norm_gamma & 15) == 0 && norm->norm_step_stride % 4 == 0 &&
+                    norm->norm_batch_stride % 4 == 0 && norm->ld_norm_ssq >= d / 32,
+                "v2a_dwconv: the folded norm needs out_bf16, norm_gamma, norm_ssq, d %% 32 == 0 (d=%d) and aligned rows", d);
+  const int TN = norm ? 4 : v2a_detail::g_dwconv_rows_per_wave;
   const int cb = (d / 4 + 63) / 64;                      // 256-channel blocks
   const int P = (N + 4 * TN - 1) / (4 * TN);             // position tiles of 4 waves x TN outputs
   const int items = P * B, ipx = (items + 7) / 8;        // work items, items per XCD label
@@ -528,10 +546,23 @@ extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float*
   const int rounds = (ipx + cap - 1) / cap;
   const int walkers = (ipx + rounds - 1) / rounds;
   dim3 grid(cb, walkers * 8), block(256);
-  if (TN == 8) hipLaunchKernelGGL((dwconv_kernel<31, 8>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
-  else if (TN == 6) hipLaunchKernelGGL((dwconv_kernel<31, 6>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
-  else hipLaunchKernelGGL((dwconv_kernel<31, 4>), grid, block, 0, (hipStream_t)stream, x, out, wt, bias, B, N, d, len, P, walkers);
+  const v2a_dwconv_norm none{};
+  hipStream_t s = (hipStream_t)stream;
+  if (norm) hipLaunchKernelGGL((dwconv_kernel<31, 4, true>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, *norm);
+  else if (TN == 6) hipLaunchKernelGGL((dwconv_kernel<31, 6, false>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, none);
+  else hipLaunchKernelGGL((dwconv_kernel<31, 4, false>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, none);
   return v2a_check_launch("v2a_dwconv_silu_residual");
+}
+
+extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias, int32_t B,
+                                        int32_t N, int32_t d, int32_t ksize, const int32_t* len, v2a_stream_t stream) {
+  return dwconv_launch(x, out, wt, bias, B, N, d, ksize, len, nullptr, stream);
+}
+
+extern "C" int v2a_dwconv_silu_residual_norm(const float* x, float* out, const float* wt, const float* bias, int32_t B, int32_t N, int32_t d,
+                                             int32_t ksize, const int32_t* len, const v2a_dwconv_norm* norm, v2a_stream_t stream) {
+  V2A_REQUIRE(norm != nullptr, "v2a_dwconv_silu_residual_norm: null norm arguments");
+  return dwconv_launch(x, out, wt, bias, B, N, d, ksize, len, norm, stream);
 }
 
 extern "C" int v2a_rope_inplace(void* qk, int32_t dtype, int64_t rows, int64_t row_stride, int32_t nheads,

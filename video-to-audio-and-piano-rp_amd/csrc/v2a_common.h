@@ -60,6 +60,15 @@ __device__ __forceinline__ float gelu_fast_f(float x) {
   return 0.5f * x * (1.0f + copysignf(erfz, x));
 }
 
+// Sum over the 8 lanes of an aligned lane octet, left in every lane of it: three DPP adds (swap neighbours, swap pairs, mirror the
+// half row), no LDS traffic (a __shfl_xor is a ds_bpermute).
+__device__ __forceinline__ float octet_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+
 // step vector address: base + step[0]*step_stride + batch*batch_stride
 __device__ __forceinline__ const float* step_vec(const float* base, const int32_t* step, int64_t step_stride,
                                                  int64_t batch_stride, int64_t batch) {

@@ -234,6 +234,9 @@ class DiTEngine:
         # ones spread over every CU (+3.5 % end to end); -1 = the library's stand-alone choice
         self.side_tile = 0 if multi_stream else -1
         self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
+        # bf16 mode: every RMSNorm of the layer stack is folded into the kernel before it (gamma on the bf16 operand it writes,
+        # sums of squares per 32 columns) and the GEMM after it (1 / rms per row in the epilogue): no norm launches
+        self.fold_norm = True
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
@@ -279,6 +282,8 @@ class DiTEngine:
         for s, d, attn, ff in (("a", D, W0["a_attn"], W0["a_ff"]), ("t", Dt, W0["t_attn"], W0["t_ff"]),
                                ("f", Df, W0["f_attn"], W0["f_ff"])):
             p[f"hn_{s}"] = e(rows, w2 * d, dt=cd)
+            # folded RMSNorm: sums of squares per 32 columns of the row to be normed; rows padded with zeros to whole float4
+            p[f"ssq_{s}"] = torch.zeros(rows, (d // 32 + 3) // 4 * 4, device=dev)
             p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=self.ad)
             p[f"ao_{s}"] = e(rows, w2 * attn.inner, dt=cd)
             p[f"ffh_{s}"] = e(rows, w2 * ff.inner, dt=cd)
@@ -365,6 +370,30 @@ class DiTEngine:
         else:
             L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, step=p["step"], gamma_step_stride=ss, rows_per_batch=p["N"], split=self.split)
 
+    def _fold(self):
+        c = self.cfg
+        return (self.fold_norm and not self.split and self.cd == torch.bfloat16
+                and all(d % 32 == 0 and d <= 1280 for d in (c.dim, c.dim_text, c.dim_frames)))
+
+    def _nprod_ada(self, layer, slot, switch_row=0):
+        """Producer side of a folded AdaptiveRMSNorm (audio stream): kwargs for the RESID / GATE_RESID GEMM or the conv that
+        writes the rows to be normed.  switch_row: rows from there on take the NEXT slot's gamma (the null half of a CFG
+        batch skips cross-attention, so its next norm is the feed-forward's)."""
+        p, D = self.plan, self.cfg.dim
+        ss = p["norm_tab"].stride(0)
+        kw = dict(norm_gamma=p["norm_tab"][0, layer, slot], norm_ssq=p["ssq_a"], rows_per_batch=p["N"])
+        if p["per_sample_t"]:
+            kw["norm_batch_stride"] = ss
+        else:
+            kw.update(step=p["step"], norm_step_stride=ss)
+        if switch_row:
+            kw.update(norm_switch_row=switch_row, norm_switch_offset=D)
+        return kw
+
+    def _ncons(self, s, d):
+        """Consumer side: the GEMM whose A operand is the un-normalised, gamma-scaled bf16 copy applies 1 / rms per row."""
+        return dict(row_ssq=self.plan[f"ssq_{s}"], row_norm_dim=d) if self._fold() else {}
+
     def _gate_kw(self, layer, slot):
         p = self.plan
         tab = p["gate_tab"][0, layer, slot]
@@ -427,14 +456,23 @@ class DiTEngine:
         lens = p["seq_len"] if p["ragged"] else None
         cv = ly[f"{s}_conv"]
         hint = dict(tile_hint=self._side_hint())
+        fold = self._fold()
+        hn, ssq = p[f"hn_{s}"], p[f"ssq_{s}"]
+        cons = dict(**hint, **self._ncons(s, d))
         if 0 in parts:
-            L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
-            self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g1"])
+            if fold:
+                L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens,
+                         norm=dict(out_bf16=hn, gamma=ly[f"{s}_g1"], ssq=ssq))
+            else:
+                L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
+                self._norm_plain(dst, hn, rows, d, ly[f"{s}_g1"])
         if 1 in parts:
-            self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
+            prod = dict(out_bf16=hn, ld_out_bf16=d, norm_gamma=ly[f"{s}_g2"], norm_ssq=ssq) if fold else {}
+            self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint, **prod), cons)
         if 2 in parts:
-            self._norm_plain(dst, p[f"hn_{s}"], rows, d, ly[f"{s}_g2"])
-            self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), hint)
+            if not fold:
+                self._norm_plain(dst, hn, rows, d, ly[f"{s}_g2"])
+            self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), cons)
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
@@ -633,10 +671,25 @@ class DiTEngine:
             dst = xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
-            L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
+            fold = self._fold()
+            cons = self._ncons("a", D)
             x = dst
-            self._norm_ada(x, p["hn_a"], rows, D, i, 0)
-            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), **mh))
+            r2 = nctx * N
+            if fold:
+                n0 = self._nprod_ada(i, 0)
+                L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens,
+                         norm=dict(out_bf16=p["hn_a"], gamma=n0["norm_gamma"], ssq=p["ssq_a"], step=n0.get("step"),
+                                   step_stride=n0.get("norm_step_stride", 0), batch_stride=n0.get("norm_batch_stride", 0)))
+                # the norm after self-attention is cross-attention's (slot 1) for the rows that have a context, the
+                # feed-forward's (slot 2) for the rest
+                n1 = self._nprod_ada(i, 1, switch_row=r2 if r2 < rows else 0) if nctx > 0 else self._nprod_ada(i, 2)
+                n1 = {k: v for k, v in n1.items() if k not in ("step", "rows_per_batch")}       # the gate already passes them
+                prod1 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n1)
+            else:
+                L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
+                self._norm_ada(x, p["hn_a"], rows, D, i, 0)
+                prod1 = {}
+            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), **mh, **prod1), cons)
             if not last and self.interleave_capture:
                 for part in (0, 1):
                     with _On(st):
@@ -649,14 +702,14 @@ class DiTEngine:
                         self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df, (part,))
             if nctx > 0:
                 A2 = ly["a_attn2"]
-                r2 = nctx * N
-                self._norm_ada(x, p["hn_a"], r2, D, i, 1)
+                if not fold:
+                    self._norm_ada(x, p["hn_a"], r2, D, i, 1)
                 q2 = p["q2"]
                 if self.rope_cross and self._fuse_rope:
                     self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad,
-                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N)
+                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons)
                 else:
-                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad)
+                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad, **cons)
                     if self.rope_cross:
                         L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
                                table=p["rope"], layout=self.rope_layout)
@@ -672,10 +725,15 @@ class DiTEngine:
                             scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc)
                 if self.split:
                     L.split_bf16(aout, p["ao_a"], rows=r2, d=inner)
+                prod2 = {}
+                if fold:
+                    n2 = {k: v for k, v in self._nprod_ada(i, 2).items() if k not in ("step", "rows_per_batch")}
+                    prod2 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n2)
                 self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
-                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh)
-            self._norm_ada(x, p["hn_a"], rows, D, i, 2)
-            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh))
+                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh, **prod2)
+            if not fold:
+                self._norm_ada(x, p["hn_a"], rows, D, i, 2)
+            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh), cons)
             if not last:
                 if not self.cross_on_main:
                     eA = rec(main)             # x of the next layer is ready
