@@ -53,6 +53,22 @@ def main():
             out = torch.empty(M, N, device=dev)
             kw = dict(epilogue=_lib.EPI_RESID, resid=res)
             ref = res + a.float() @ w.float().t()
+        elif epi in ("gate", "gate_prod"):             # GATE_RESID in place (+ folded-RMSNorm producer with a switch row)
+            out = res.clone()
+            gate = torch.rand(4, N, device=dev)
+            step = torch.tensor([1], dtype=torch.int32, device=dev)
+            kw = dict(epilogue=_lib.EPI_GATE_RESID, resid=out, gate=gate, step=step, gate_step_stride=N, rows_per_batch=782)
+            if epi == "gate_prod":
+                kw.update(out_bf16=torch.empty(M, N, device=dev, dtype=torch.bfloat16), norm_gamma=torch.ones(4, 2, N, device=dev),
+                          norm_step_stride=2 * N, norm_switch_row=M // 2, norm_switch_offset=N, norm_ssq=torch.zeros(M, N // 32, device=dev))
+            ref = None
+        elif epi in ("resid_shadow", "resid_prod"):     # RESID + bf16 shadow / + folded-RMSNorm producer (gamma, sums of squares)
+            out = torch.empty(M, N, device=dev)
+            sh = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            kw = dict(epilogue=_lib.EPI_RESID, resid=res, out_bf16=sh)
+            if epi == "resid_prod":
+                kw.update(norm_gamma=torch.ones(N, device=dev), norm_ssq=torch.zeros(M, N // 32, device=dev))
+            ref = res + a.float() @ w.float().t()
         elif epi == "geglu":
             out = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
             kw = dict(epilogue=_lib.EPI_GEGLU, ldo=N // 2)

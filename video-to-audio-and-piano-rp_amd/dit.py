@@ -234,8 +234,8 @@ class DiTEngine:
         # ones spread over every CU (+3.5 % end to end); -1 = the library's stand-alone choice
         self.side_tile = 0 if multi_stream else -1
         self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
-        # bf16 mode: every RMSNorm of the layer stack is folded into the kernel before it (gamma on the bf16 operand it writes,
-        # sums of squares per 32 columns) and the GEMM after it (1 / rms per row in the epilogue): no norm launches
+        # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
+        # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
@@ -375,6 +375,12 @@ class DiTEngine:
         return (self.fold_norm and not self.split and self.cd == torch.bfloat16
                 and all(d % 32 == 0 and d <= 1280 for d in (c.dim, c.dim_text, c.dim_frames)))
 
+    def _fold_gemm(self):
+        """... into a GEMM epilogue only up to two clips: the extra bf16 row pieces cost an out-projection launch 2 us of 24 at
+        one clip (a norm launch: 7.7 us) but 20-26 us of 58 at 8 clips per GPU, more than the 16.5 us norm launch they replace
+        (the conv fold wins at every size: 46 us against 49 + 16.5)."""
+        return self._fold() and self.plan["rows"] <= 3200
+
     def _nprod_ada(self, layer, slot, switch_row=0):
         """Producer side of a folded AdaptiveRMSNorm (audio stream): kwargs for the RESID / GATE_RESID GEMM or the conv that
         writes the rows to be normed.  switch_row: rows from there on take the NEXT slot's gamma (the null half of a CFG
@@ -456,9 +462,10 @@ class DiTEngine:
         lens = p["seq_len"] if p["ragged"] else None
         cv = ly[f"{s}_conv"]
         hint = dict(tile_hint=self._side_hint())
-        fold = self._fold()
+        fold, fold2 = self._fold(), self._fold_gemm()
         hn, ssq = p[f"hn_{s}"], p[f"ssq_{s}"]
         cons = dict(**hint, **self._ncons(s, d))
+        cons2 = cons if fold2 else hint
         if 0 in parts:
             if fold:
                 L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens,
@@ -467,12 +474,12 @@ class DiTEngine:
                 L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
                 self._norm_plain(dst, hn, rows, d, ly[f"{s}_g1"])
         if 1 in parts:
-            prod = dict(out_bf16=hn, ld_out_bf16=d, norm_gamma=ly[f"{s}_g2"], norm_ssq=ssq) if fold else {}
+            prod = dict(out_bf16=hn, ld_out_bf16=d, norm_gamma=ly[f"{s}_g2"], norm_ssq=ssq) if fold2 else {}
             self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint, **prod), cons)
         if 2 in parts:
-            if not fold:
+            if not fold2:
                 self._norm_plain(dst, hn, rows, d, ly[f"{s}_g2"])
-            self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), cons)
+            self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), cons2)
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
@@ -671,24 +678,26 @@ class DiTEngine:
             dst = xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
-            fold = self._fold()
+            fold, fold2 = self._fold(), self._fold_gemm()       # norm after the conv / norms after GEMM epilogues
             cons = self._ncons("a", D)
+            cons2 = cons if fold2 else {}
             x = dst
             r2 = nctx * N
+            prod1 = {}
             if fold:
                 n0 = self._nprod_ada(i, 0)
                 L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens,
                          norm=dict(out_bf16=p["hn_a"], gamma=n0["norm_gamma"], ssq=p["ssq_a"], step=n0.get("step"),
                                    step_stride=n0.get("norm_step_stride", 0), batch_stride=n0.get("norm_batch_stride", 0)))
+            else:
+                L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
+                self._norm_ada(x, p["hn_a"], rows, D, i, 0)
+            if fold2:
                 # the norm after self-attention is cross-attention's (slot 1) for the rows that have a context, the
                 # feed-forward's (slot 2) for the rest
                 n1 = self._nprod_ada(i, 1, switch_row=r2 if r2 < rows else 0) if nctx > 0 else self._nprod_ada(i, 2)
                 n1 = {k: v for k, v in n1.items() if k not in ("step", "rows_per_batch")}       # the gate already passes them
                 prod1 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n1)
-            else:
-                L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
-                self._norm_ada(x, p["hn_a"], rows, D, i, 0)
-                prod1 = {}
             self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), **mh, **prod1), cons)
             if not last and self.interleave_capture:
                 for part in (0, 1):
@@ -702,14 +711,14 @@ class DiTEngine:
                         self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df, (part,))
             if nctx > 0:
                 A2 = ly["a_attn2"]
-                if not fold:
+                if not fold2:
                     self._norm_ada(x, p["hn_a"], r2, D, i, 1)
                 q2 = p["q2"]
                 if self.rope_cross and self._fuse_rope:
                     self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad,
-                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons)
+                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons2)
                 else:
-                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad, **cons)
+                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad, **cons2)
                     if self.rope_cross:
                         L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
                                table=p["rope"], layout=self.rope_layout)
@@ -726,14 +735,14 @@ class DiTEngine:
                 if self.split:
                     L.split_bf16(aout, p["ao_a"], rows=r2, d=inner)
                 prod2 = {}
-                if fold:
+                if fold2:
                     n2 = {k: v for k, v in self._nprod_ada(i, 2).items() if k not in ("step", "rows_per_batch")}
                     prod2 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n2)
                 self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
                          epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh, **prod2)
-            if not fold:
+            if not fold2:
                 self._norm_ada(x, p["hn_a"], rows, D, i, 2)
-            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh), cons)
+            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh), cons2)
             if not last:
                 if not self.cross_on_main:
                     eA = rec(main)             # x of the next layer is ready
