@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--cfm-steps", type=int, default=32)
     ap.add_argument("--cfg-strength", type=float, default=2.0)
     ap.add_argument("--frames", type=int, default=750)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--v2p", action="store_true", help="configs[3]: non-zero piano roll, 64 steps")
     ap.add_argument("--cascade", type=int, default=1, help="configs[4]: this many sequential sample() passes per step (the "
                     "reference has no CoT-guidance code, SURVEY 8d: defined here as cascaded 32-step passes, each pass "

@@ -225,7 +225,8 @@ typedef struct v2a_attn_args {
   const int32_t* kv_len; /* [B] or NULL (= Nk) */
   const int32_t* q_len;  /* [B] or NULL (= Nq) */
   float scale, softclamp;
-  int32_t dtype;         /* compute dtype of q,k,v,gate,out */
+  int32_t dtype;         /* V2A_F32 / V2A_BF16: dtype of q,k,v,gate,out and of the arithmetic; V2A_BF16_SPLIT: fp32 tensors,
+                          * products as three bf16 MFMA passes over hi | lo operand planes (the bf16x3 mode) */
 } v2a_attn_args;
 
 int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);

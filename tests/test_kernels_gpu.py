@@ -353,13 +353,17 @@ def _attn_ref(q, k, v, gate, kv_len, q_len, clamp=50.0):
     return out * qm[:, None, :, None]
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, "split"])
 @pytest.mark.parametrize("B,H,Nq,Nk,kv_len,q_len", [(2, 2, 44, 44, [44, 30], [44, 30]), (1, 16, 782, 782, [782], [782]),
                                                   (2, 3, 100, 5, [5, 3], [100, 70]), (1, 1, 65, 129, [129], [65])])
 @pytest.mark.parametrize("clamp", [50.0, 80.0])
 def test_attention(L, dt, B, H, Nq, Nk, kv_len, q_len, clamp):
     """clamp 50 (the reference's value): the bf16 kernel runs without a running maximum (bounded weights); clamp 80: with
-    the online maximum (2^(80 log2 e) is too close to fp32's range to skip it)."""
+    the online maximum (2^(80 log2 e) is too close to fp32's range to skip it).  dt "split": fp32 tensors, products as
+    three bf16 MFMA passes over hi | lo planes (the bf16x3 mode's kernel), held to 2e-4."""
+    code = None
+    if dt == "split":
+        dt, code = torch.float32, L.BF16_SPLIT
     g = _g(Nq + Nk)
     q = torch.randn(B, H, Nq, 64, generator=g) * 2.0          # |logits| large enough that the tanh clamp bends them
     k = torch.randn(B, H, Nk, 64, generator=g) * 2.0
@@ -381,9 +385,9 @@ def test_attention(L, dt, B, H, Nq, Nk, kv_len, q_len, clamp):
                          Nq * (inner + 16), Nk * 2 * inner, Nk * 2 * inner, Nq * (inner + 16), Nq * inner),
                 B=B, H=H, Nq=Nq, Nk=Nk, kv_len=torch.tensor(kv_len, dtype=torch.int32, device=DEV),
                 q_len=torch.tensor(q_len, dtype=torch.int32, device=DEV), scale=0.125, softclamp=clamp,
-                dtype=L.dt_code(dt))
+                dtype=L.dt_code(dt) if code is None else code)
     got = out.float().cpu().reshape(B, Nq, H, 64).permute(0, 2, 1, 3)
-    tol = 2e-5 if dt == torch.float32 else 2e-2
+    tol = (2e-5 if code is None else 2e-4) if dt == torch.float32 else 2e-2
     torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
 
 

@@ -382,7 +382,7 @@ def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=N
     a.kv_len, a.q_len = _p(kv_len), _p(q_len)
     a.scale, a.softclamp, a.dtype = scale, softclamp, dtype
     esz = 2 if dtype == BF16 else 4
-    _launch("attention<%s>" % ("bf16" if dtype == BF16 else "f32"), 4.0 * B * H * Nq * Nk * 64,
+    _launch("attention<%s>" % {BF16: "bf16", F32: "f32", BF16_SPLIT: "bf16x3"}[dtype], 4.0 * B * H * Nq * Nk * 64,
             B * H * 64 * (2 * Nq + 2 * Nk) * esz, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
 
 

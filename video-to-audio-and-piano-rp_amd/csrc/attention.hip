@@ -371,13 +371,304 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-bf16 MFMA flash kernel for fp32 q, k, v, gate, out (the bf16x3 compute mode): the same schedule as attn_mfma_kernel
+// with every operand as hi | lo bf16 planes (hi = bf16(v), lo = bf16(v - hi)) and every product as three MFMAs
+//   K Q^T  ~ Kh Qh^T + Kl Qh^T + Kh Ql^T        V^T P^T ~ Vh^T Ph^T + Vl^T Ph^T + Vh^T Pl^T
+// (the lo x lo term is 2^-16 of the product and is dropped, as in the bf16x3 GEMMs).  K / V tiles are split on their way from
+// the fp32 rows into LDS (four planes per stage), q once per workgroup, P in registers after the fp32 softmax.  Replaces the
+// one-query-per-lane fp32 VALU kernel in that mode: 518 -> ~70 us per self-attention launch at one clip.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bf16_t ha = (bf16_t)a[e], hb = (bf16_t)b[e];
+    hi[e] = ha;
+    hi[4 + e] = hb;
+    lo[e] = (bf16_t)(a[e] - (float)ha);
+    lo[4 + e] = (bf16_t)(b[e] - (float)hb);
+  }
+}
+
+template <int NG, int CLAMP>
+__global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p) {
+  constexpr int TK = 64, VLD = 68;
+  constexpr int K_ELEMS = TK * 64, V_ELEMS = 64 * VLD;
+  constexpr int STAGE = 2 * (K_ELEMS + V_ELEMS);          // Kh | Kl | Vh | Vl
+  constexpr int RING = 2 * STAGE;
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  bf16_t* lds = lds_dyn + grp * RING;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int query = q0 + lr;
+  const int kvn = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;
+  const float* Q = reinterpret_cast<const float*>(p.q) + b * p.qbs + h * 64;
+  const float* Kg = reinterpret_cast<const float*>(p.k) + b * p.kbs + h * 64;
+  const float* Vg = reinterpret_cast<const float*>(p.v) + b * p.vbs + h * 64;
+
+  bf16x8 qh[2], ql[2];
+  {
+    const int qr = query < p.Nq ? query : p.Nq - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float* qp = Q + (int64_t)qr * p.qrs + 32 * kk + 8 * g;
+      split8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qh[kk], ql[kk]);
+    }
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = CLAMP == 2 ? 0.f : -INFINITY, l = 0.f;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float zc = p.clamp > 0.f ? 2.0f * LOG2E * p.scale / p.clamp : p.scale * LOG2E;
+  const float c2 = p.clamp * LOG2E;
+
+  // staging registers (fp32 as loaded; split when written to LDS): K rows (tid>>3)+32i chunk tid&7; V key pair kp = lane&31,
+  // d-chunk = 2*wave + (lane>>5).  Two sets, as in the bf16 kernel.
+  struct Raw {
+    f32x4 a, b;
+  };
+  Raw kregA[2], vregA[2], kregB[2], vregB[2];
+  const int kchunk = tid & 7, krow = tid >> 3;
+  const int kp = lane & 31, dch = wave * 2 + (lane >> 5);
+  auto load_tile = [&](int j0, Raw (&kreg)[2], Raw (&vreg)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = j0 + krow + 32 * i;
+      key = key < p.Nk ? key : p.Nk - 1;
+      const float* kpz = Kg + (int64_t)key * p.krs + kchunk * 8;
+      kreg[i].a = *reinterpret_cast<const f32x4*>(kpz);
+      kreg[i].b = *reinterpret_cast<const f32x4*>(kpz + 4);
+      int vk = j0 + 2 * kp + i;
+      vk = vk < p.Nk ? vk : p.Nk - 1;
+      const float* vpz = Vg + (int64_t)vk * p.vrs + dch * 8;
+      vreg[i].a = *reinterpret_cast<const f32x4*>(vpz);
+      vreg[i].b = *reinterpret_cast<const f32x4*>(vpz + 4);
+    }
+  };
+  auto store_tile = [&](bf16_t* base, const Raw (&kreg)[2], const Raw (&vreg)[2]) {
+    bf16_t* ksh = base;
+    bf16_t* ksl = base + K_ELEMS;
+    bf16_t* vth = base + 2 * K_ELEMS;
+    bf16_t* vtl = vth + V_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = krow + 32 * i;
+      bf16x8 hi, lo;
+      split8(kreg[i].a, kreg[i].b, hi, lo);
+      const int off = row * 64 + ((kchunk ^ (row & 7)) << 3);
+      *reinterpret_cast<bf16x8*>(ksh + off) = hi;
+      *reinterpret_cast<bf16x8*>(ksl + off) = lo;
+    }
+    bf16x8 h0, l0, h1, l1;
+    split8(vreg[0].a, vreg[0].b, h0, l0);
+    split8(vreg[1].a, vreg[1].b, h1, l1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      bf16x2 ph, pl;
+      ph[0] = h0[i];
+      ph[1] = h1[i];
+      pl[0] = l0[i];
+      pl[1] = l1[i];
+      *reinterpret_cast<bf16x2*>(vth + (dch * 8 + i) * VLD + 2 * kp) = ph;
+      *reinterpret_cast<bf16x2*>(vtl + (dch * 8 + i) * VLD + 2 * kp) = pl;
+    }
+  };
+
+  const int ntiles_all = (kvn + TK - 1) / TK;
+  const int nit = (ntiles_all + NG - 1) / NG;
+  const int ntiles = (ntiles_all - grp + NG - 1) / NG;
+  if (ntiles > 0) {
+    load_tile(grp * TK, kregA, vregA);
+    store_tile(lds, kregA, vregA);
+  }
+  if (ntiles > 1) load_tile((NG + grp) * TK, kregA, vregA);
+  __syncthreads();
+  for (int jt = 0; jt < nit; ++jt) {
+    if (jt >= ntiles) {
+      __syncthreads();
+      continue;
+    }
+    const bf16_t* ksh = lds + (jt & 1) * STAGE;
+    const bf16_t* ksl = ksh + K_ELEMS;
+    const bf16_t* vth = ksh + 2 * K_ELEMS;
+    const bf16_t* vtl = vth + V_ELEMS;
+    if (jt + 2 < ntiles) {
+      if (jt & 1) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
+      else load_tile(((jt + 2) * NG + grp) * TK, kregB, vregB);
+    }
+    // ---- S^T = K Q^T in three passes
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = 16 * t + lr;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int off = row * 64 + (((kk * 4 + g) ^ (row & 7)) << 3);
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(ksh + off);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(ksl + off);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[kk], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[kk], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[kk], s[t], 0, 0, 0);
+      }
+    }
+    const int j0 = (jt * NG + grp) * TK;
+    if constexpr (CLAMP == 2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
+          s[t][j] = __builtin_amdgcn_exp2f(fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2));
+        }
+      if (j0 + TK > kvn) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j0 + 16 * t + 4 * g + j >= kvn) s[t][j] = 0.f;
+      }
+    } else {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v;
+          if constexpr (CLAMP == 1) {
+            const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
+            v = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2);
+          } else {
+            v = s[t][j] * zc;
+          }
+          s[t][j] = v;
+        }
+      if (j0 + TK > kvn) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j0 + 16 * t + 4 * g + j >= kvn) s[t][j] = -INFINITY;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tmax = fmaxf(tmax, s[t][j]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      m = mn;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[dt][j] *= alpha;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[t][j] = __builtin_amdgcn_exp2f(s[t][j] - mn);
+    }
+    // fp32 weights -> row sum, hi | lo operand planes
+    bf16x8 pfh[2], pfl[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = s[t][j];
+        l += pv;
+        const bf16_t hv = (bf16_t)pv;
+        pfh[t >> 1][(t & 1) * 4 + j] = hv;
+        pfl[t >> 1][(t & 1) * 4 + j] = (bf16_t)(pv - (float)hv);
+      }
+    // ---- O^T += V^T P^T in three passes
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int voff = (16 * dt + lr) * VLD + 4 * g;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        bf16x8 vfh, vfl;
+        {
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vth + voff + 32 * ks2);
+          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vth + voff + 32 * ks2 + 16);
+          const bf16x4 lo2 = *reinterpret_cast<const bf16x4*>(vtl + voff + 32 * ks2);
+          const bf16x4 hi2 = *reinterpret_cast<const bf16x4*>(vtl + voff + 32 * ks2 + 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vfh[j] = lo[j];
+            vfh[4 + j] = hi[j];
+            vfl[j] = lo2[j];
+            vfl[4 + j] = hi2[j];
+          }
+        }
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pfh[ks2], o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, pfl[ks2], o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, pfh[ks2], o[dt], 0, 0, 0);
+      }
+    }
+    if (jt + 1 < ntiles) {
+      bf16_t* nb = lds + ((jt + 1) & 1) * STAGE;
+      if ((jt + 1) & 1) store_tile(nb, kregA, vregA);
+      else store_tile(nb, kregB, vregB);
+    }
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if constexpr (NG == 2) {
+    float* xch = reinterpret_cast<float*>(lds_dyn + RING);          // 18 floats x 256 lanes = 18 KB, group 1's dead ring
+    __syncthreads();
+    if (grp == 1) {
+      float* dst = xch + tid;
+      dst[0] = m;
+      dst[256] = l;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(2 + dt * 4 + j) * 256] = o[dt][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float* src = xch + tid;
+    const float m2 = src[0], l2 = src[256];
+    const float mn = fmaxf(m, m2);
+    const float a1 = __builtin_amdgcn_exp2f(m - mn), a2 = (m2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] = o[dt][j] * a1 + src[(2 + dt * 4 + j) * 256] * a2;
+  }
+  if (query >= p.Nq) return;
+  const int qn = p.q_len ? min(p.q_len[b], p.Nq) : p.Nq;
+  float gt = 1.f;
+  if (p.gate) gt = sigmoid_f(reinterpret_cast<const float*>(p.gate)[b * p.gbs + (int64_t)query * p.grs + h]);
+  const float f = (query < qn && l > 0.f) ? gt / l : 0.f;
+  float* op = reinterpret_cast<float*>(p.out) + b * p.obs + (int64_t)query * p.ors + h * 64 + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(op + 16 * dt) = o[dt] * f;
+}
+
+template <int NG, int CLAMP>
+void launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 68) * sizeof(bf16_t);
+  auto kern = attn_mfma_split_kernel<NG, CLAMP>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  (void)attr;
+  hipLaunchKernelGGL(kern, grid, dim3(256 * NG), smem, s, p);
+}
+
 }  // namespace
 
 extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   V2A_REQUIRE(a != nullptr, "v2a_attention: null args");
   V2A_REQUIRE(a->q && a->k && a->v && a->out, "v2a_attention: null tensor");
   V2A_REQUIRE(a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, "v2a_attention: B=%d H=%d Nq=%d Nk=%d", a->B, a->H, a->Nq, a->Nk);
-  V2A_REQUIRE(a->dtype == V2A_F32 || a->dtype == V2A_BF16, "v2a_attention: dtype %d", a->dtype);
+  V2A_REQUIRE(a->dtype == V2A_F32 || a->dtype == V2A_BF16 || a->dtype == V2A_BF16_SPLIT, "v2a_attention: dtype %d", a->dtype);
   AttnParams p{};
   p.q = a->q; p.k = a->k; p.v = a->v; p.gate = a->gate; p.out = a->out;
   p.qrs = a->q_row_stride; p.krs = a->k_row_stride; p.vrs = a->v_row_stride; p.grs = a->gate_row_stride; p.ors = a->out_row_stride;
@@ -387,7 +678,25 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   p.scale = a->scale; p.clamp = a->softclamp;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((a->Nq + 63) / 64, a->H, a->B), block(64);
-  if (a->dtype == V2A_F32) {
+  if (a->dtype == V2A_BF16_SPLIT) {
+    // fp32 tensors, split-bf16 MFMA arithmetic (bf16x3 mode); 16-byte aligned head slices and output rows, else the VALU kernel
+    const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) == 0 && a->q_row_stride % 4 == 0 &&
+                         a->k_row_stride % 4 == 0 && a->v_row_stride % 4 == 0 && a->out_row_stride % 4 == 0 && a->q_batch_stride % 4 == 0 &&
+                         a->k_batch_stride % 4 == 0 && a->v_batch_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
+    const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
+    const int cl = a->softclamp > 0.f ? (a->softclamp * 1.4426950408889634f <= 100.f ? 2 : 1) : 0;
+    if (!aligned) {
+      hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
+    } else if (a->Nk > 128) {
+      if (cl == 2) launch_attn_split<2, 2>(p, g64, s);
+      else if (cl == 1) launch_attn_split<2, 1>(p, g64, s);
+      else launch_attn_split<2, 0>(p, g64, s);
+    } else {
+      if (cl == 2) launch_attn_split<1, 2>(p, g64, s);
+      else if (cl == 1) launch_attn_split<1, 1>(p, g64, s);
+      else launch_attn_split<1, 0>(p, g64, s);
+    }
+  } else if (a->dtype == V2A_F32) {
     hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
   } else {
     // MFMA path needs 16-byte aligned head slices for its vector loads and 8-byte aligned output rows

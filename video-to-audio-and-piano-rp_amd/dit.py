@@ -250,7 +250,8 @@ class DiTEngine:
         self.cd = torch.float32 if compute == "fp32" else torch.bfloat16      # dtype of GEMM operand buffers
         self.cdc = L.F32 if compute == "fp32" else L.BF16                      # compute dtype of the GEMMs
         self.ad = torch.bfloat16 if compute == "bf16" else torch.float32      # dtype of q | k | v | gate and attention outputs
-        self.adc = L.BF16 if compute == "bf16" else L.F32
+        # attention arithmetic: bf16 MFMA / exact fp32 on the VALU / fp32 tensors with split-bf16 MFMA products (bf16x3)
+        self.adc = {"bf16": L.BF16, "fp32": L.F32, "bf16x3": L.BF16_SPLIT}[compute]
         self.rope_layout = {"interleaved": 0, "half": 1}[rope_layout]
         self.rope_cross = rope_cross
         self.zero_masked_queries = zero_masked_queries
