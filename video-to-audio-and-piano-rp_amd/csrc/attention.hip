@@ -653,6 +653,242 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
   for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(op + 16 * dt) = o[dt] * f;
 }
 
+// ------------------------------------------------------------------------------------------
+// fp32 MFMA flash kernel (the fp32 compute mode): the same schedule on v_mfma_f32_16x16x4_f32 -- fp32 operands, fp32 products,
+// fp32 accumulation, as in the exact-fp32 GEMM.  The MFMA's k slot (c, g) carries head dimension 16 g + c for K Q^T, so a lane
+// reads its 16 K values of a key as four ds_read_b128, and key 16 t + 4 g + j for V^T P^T, so the S^T accumulator register j of
+// a lane IS the P^T operand and the V^T fragment is one ds_read_b128 (j = 0..3).  K tiles in LDS as [key][68] floats, V tiles
+// transposed to [d][68].  Replaces the one-query-per-lane VALU kernel for aligned shapes: 518 -> ~80 us per launch.
+// ------------------------------------------------------------------------------------------
+template <int NG, int CLAMP>
+__global__ __launch_bounds__(256 * NG) void attn_mfma_f32_kernel(AttnParams p) {
+  constexpr int TK = 64, LD = 68;
+  constexpr int T_ELEMS = 64 * LD;                      // floats of one K or V^T tile
+  constexpr int STAGE = 2 * T_ELEMS;                    // K | V^T
+  constexpr int RING = 2 * STAGE;
+  extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  float* lds = lds_f32 + grp * RING;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int query = q0 + lr;
+  const int kvn = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;
+  const float* Q = reinterpret_cast<const float*>(p.q) + b * p.qbs + h * 64;
+  const float* Kg = reinterpret_cast<const float*>(p.k) + b * p.kbs + h * 64;
+  const float* Vg = reinterpret_cast<const float*>(p.v) + b * p.vbs + h * 64;
+
+  f32x4 qf[4];                                           // q[query][16 g + 4 c4 + e]
+  {
+    const int qr = query < p.Nq ? query : p.Nq - 1;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) qf[c4] = *reinterpret_cast<const f32x4*>(Q + (int64_t)qr * p.qrs + 16 * g + 4 * c4);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = CLAMP == 2 ? 0.f : -INFINITY, l = 0.f;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float zc = p.clamp > 0.f ? 2.0f * LOG2E * p.scale / p.clamp : p.scale * LOG2E;
+  const float c2 = p.clamp * LOG2E;
+
+  struct Raw {
+    f32x4 a, b;
+  };
+  Raw kregA[2], vregA[2], kregB[2], vregB[2];
+  const int kchunk = tid & 7, krow = tid >> 3;
+  const int kp = lane & 31, dch = wave * 2 + (lane >> 5);
+  auto load_tile = [&](int j0, Raw (&kreg)[2], Raw (&vreg)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = j0 + krow + 32 * i;
+      key = key < p.Nk ? key : p.Nk - 1;
+      const float* kpz = Kg + (int64_t)key * p.krs + kchunk * 8;
+      kreg[i].a = *reinterpret_cast<const f32x4*>(kpz);
+      kreg[i].b = *reinterpret_cast<const f32x4*>(kpz + 4);
+      int vk = j0 + 2 * kp + i;
+      vk = vk < p.Nk ? vk : p.Nk - 1;
+      const float* vpz = Vg + (int64_t)vk * p.vrs + dch * 8;
+      vreg[i].a = *reinterpret_cast<const f32x4*>(vpz);
+      vreg[i].b = *reinterpret_cast<const f32x4*>(vpz + 4);
+    }
+  };
+  auto store_tile = [&](float* base, const Raw (&kreg)[2], const Raw (&vreg)[2]) {
+    float* ks = base;
+    float* vt = base + T_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* dst = ks + (krow + 32 * i) * LD + kchunk * 8;
+      *reinterpret_cast<f32x4*>(dst) = kreg[i].a;
+      *reinterpret_cast<f32x4*>(dst + 4) = kreg[i].b;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f32x2 pr;
+      pr[0] = e < 4 ? vreg[0].a[e & 3] : vreg[0].b[e & 3];
+      pr[1] = e < 4 ? vreg[1].a[e & 3] : vreg[1].b[e & 3];
+      *reinterpret_cast<f32x2*>(vt + (dch * 8 + e) * LD + 2 * kp) = pr;
+    }
+  };
+
+  const int ntiles_all = (kvn + TK - 1) / TK;
+  const int nit = (ntiles_all + NG - 1) / NG;
+  const int ntiles = (ntiles_all - grp + NG - 1) / NG;
+  if (ntiles > 0) {
+    load_tile(grp * TK, kregA, vregA);
+    store_tile(lds, kregA, vregA);
+  }
+  if (ntiles > 1) load_tile((NG + grp) * TK, kregA, vregA);
+  __syncthreads();
+  for (int jt = 0; jt < nit; ++jt) {
+    if (jt >= ntiles) {
+      __syncthreads();
+      continue;
+    }
+    const float* ks = lds + (jt & 1) * STAGE;
+    const float* vt = ks + T_ELEMS;
+    if (jt + 2 < ntiles) {
+      if (jt & 1) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
+      else load_tile(((jt + 2) * NG + grp) * TK, kregB, vregB);
+    }
+    // ---- S^T = K Q^T : 4 key tiles x 16 k-steps of 4 head dimensions
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* krowp = ks + (16 * t + lr) * LD + 16 * g;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(krowp + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[c4][e], s[t], 0, 0, 0);
+      }
+    }
+    const int j0 = (jt * NG + grp) * TK;
+    if constexpr (CLAMP == 2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
+          s[t][j] = __builtin_amdgcn_exp2f(fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2));
+        }
+      if (j0 + TK > kvn) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j0 + 16 * t + 4 * g + j >= kvn) s[t][j] = 0.f;
+      }
+    } else {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v;
+          if constexpr (CLAMP == 1) {
+            const float e = __builtin_amdgcn_exp2f(s[t][j] * zc);
+            v = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f * c2, c2);
+          } else {
+            v = s[t][j] * zc;
+          }
+          s[t][j] = v;
+        }
+      if (j0 + TK > kvn) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j0 + 16 * t + 4 * g + j >= kvn) s[t][j] = -INFINITY;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tmax = fmaxf(tmax, s[t][j]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      m = mn;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[dt][j] *= alpha;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[t][j] = __builtin_amdgcn_exp2f(s[t][j] - mn);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) l += s[t][j];
+    // ---- O^T += V^T P^T : 4 d tiles x 16 k-steps of 4 keys; the accumulator register j of S^T is the P^T operand
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const float* vrow = vt + (16 * dt + lr) * LD + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(vrow + 16 * t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j], s[t][j], o[dt], 0, 0, 0);
+      }
+    }
+    if (jt + 1 < ntiles) {
+      float* nb = lds + ((jt + 1) & 1) * STAGE;
+      if ((jt + 1) & 1) store_tile(nb, kregA, vregA);
+      else store_tile(nb, kregB, vregB);
+    }
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if constexpr (NG == 2) {
+    float* xch = lds_f32 + RING;                                    // 18 floats x 256 lanes = 18 KB, group 1's dead ring
+    __syncthreads();
+    if (grp == 1) {
+      float* dst = xch + tid;
+      dst[0] = m;
+      dst[256] = l;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(2 + dt * 4 + j) * 256] = o[dt][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float* src = xch + tid;
+    const float m2 = src[0], l2 = src[256];
+    const float mn = fmaxf(m, m2);
+    const float a1 = __builtin_amdgcn_exp2f(m - mn), a2 = (m2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[dt][j] = o[dt][j] * a1 + src[(2 + dt * 4 + j) * 256] * a2;
+  }
+  if (query >= p.Nq) return;
+  const int qn = p.q_len ? min(p.q_len[b], p.Nq) : p.Nq;
+  float gt = 1.f;
+  if (p.gate) gt = sigmoid_f(reinterpret_cast<const float*>(p.gate)[b * p.gbs + (int64_t)query * p.grs + h]);
+  const float f = (query < qn && l > 0.f) ? gt / l : 0.f;
+  float* op = reinterpret_cast<float*>(p.out) + b * p.obs + (int64_t)query * p.ors + h * 64 + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(op + 16 * dt) = o[dt] * f;
+}
+
+template <int NG, int CLAMP>
+void launch_attn_f32(const AttnParams& p, dim3 grid, hipStream_t s) {
+  constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 68) * sizeof(float);
+  auto kern = attn_mfma_f32_kernel<NG, CLAMP>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  (void)attr;
+  hipLaunchKernelGGL(kern, grid, dim3(256 * NG), smem, s, p);
+}
+
 template <int NG, int CLAMP>
 void launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 68) * sizeof(bf16_t);
@@ -697,7 +933,22 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
       else launch_attn_split<1, 0>(p, g64, s);
     }
   } else if (a->dtype == V2A_F32) {
-    hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
+    const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) == 0 && a->q_row_stride % 4 == 0 &&
+                         a->k_row_stride % 4 == 0 && a->v_row_stride % 4 == 0 && a->out_row_stride % 4 == 0 && a->q_batch_stride % 4 == 0 &&
+                         a->k_batch_stride % 4 == 0 && a->v_batch_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
+    const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
+    const int cl = a->softclamp > 0.f ? (a->softclamp * 1.4426950408889634f <= 100.f ? 2 : 1) : 0;
+    if (!aligned) {
+      hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
+    } else if (a->Nk > 128) {
+      if (cl == 2) launch_attn_f32<2, 2>(p, g64, s);
+      else if (cl == 1) launch_attn_f32<2, 1>(p, g64, s);
+      else launch_attn_f32<2, 0>(p, g64, s);
+    } else {
+      if (cl == 2) launch_attn_f32<1, 2>(p, g64, s);
+      else if (cl == 1) launch_attn_f32<1, 1>(p, g64, s);
+      else launch_attn_f32<1, 0>(p, g64, s);
+    }
   } else {
     // MFMA path needs 16-byte aligned head slices for its vector loads and 8-byte aligned output rows
     const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) == 0 && ((uintptr_t)a->out & 7) == 0 &&
