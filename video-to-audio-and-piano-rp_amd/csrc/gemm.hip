@@ -551,7 +551,13 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   if (a->epilogue == V2A_EPI_GATE_RESID) V2A_REQUIRE(a->gate != nullptr, "v2a_gemm: GATE_RESID needs gate");
   if (a->epilogue == V2A_EPI_GEGLU) V2A_REQUIRE(a->N % 32 == 0, "v2a_gemm: GEGLU needs N %% 32 == 0 (N=%d)", a->N);
   hipStream_t s = (hipStream_t)stream;
-  if (a->compute_dtype == V2A_F32) return dispatch_epi<float, false, 128, 128>(a, p, s);
+  if (a->compute_dtype == V2A_F32) {
+    // exact-fp32 kernel: 64x64 tiles while 128x128 ones would leave CUs idle (one clip: 13 x 8 tiles for N = 1024); the K order of
+    // an output element does not depend on the tile, so the result is the same bit for bit
+    const int64_t t128 = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128);
+    if (t128 < 224 && a->M > 64) return dispatch_epi<float, false, 64, 64>(a, p, s);
+    return dispatch_epi<float, false, 128, 128>(a, p, s);
+  }
   if (a->a_dtype == V2A_F32) return dispatch_epi<bf16_t, true, 128, 128>(a, p, s);
   if (a->epilogue == V2A_EPI_SIGMOID) return dispatch_epi<bf16_t, false, 128, 128>(a, p, s);
   // bf16 x bf16: LDS-DMA kernel; tile shape by how many workgroups the problem yields (256 CUs)
