@@ -120,9 +120,9 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
 //     O^T = V^T P^T (k-slot (g, jj) <-> key 16*(2ks + jj/4) + 4g + jj%4; the V^T fragment is read
 //     in the same permuted key order), so P never touches LDS;
 //   * O^T has the query on the lane again, so the rescale factor alpha is a per-lane scalar.
-// K tiles sit in LDS row-major [key][64] with the 16-B chunk XOR-swizzled by (key & 7) (conflict-free
-// ds_read_b128 A fragments); V tiles are transposed on the way in to [d][68] (136-B rows: 8-B
-// aligned, conflict-free ds_read_b64 of 4 consecutive keys).  2-deep LDS ring, register prefetch.
+// K and V tiles sit in LDS row-major [key][64] with the 16-B chunk XOR-swizzled by (key & 7): conflict-free
+// ds_read_b128 A fragments of K, and V^T fragments by the hardware-transposing ds_read_b64_tr_b16 (4 keys x 16
+// head dimensions per 16-lane group).  2-deep LDS ring, register prefetch.
 // ------------------------------------------------------------------------------------------
 
 // NG = 1: 4 waves.  NG = 2: 8 waves, wave group g takes KV tiles g, g+2, ... of the same 64 queries (own LDS
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
 // subtraction, the rescale of O and l per tile and two wave shuffles per tile disappear from a VALU-bound loop.
 template <int NG, int CLAMP>
 __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
-  constexpr int TK = 64, VLD = 68;
-  constexpr int K_ELEMS = TK * 64, V_ELEMS = 64 * VLD;
+  constexpr int TK = 64;
+  constexpr int K_ELEMS = TK * 64, V_ELEMS = TK * 64;     // both tiles row-major [key][64], 16-B chunks XOR-swizzled by (key & 7)
   constexpr int RING = 2 * (K_ELEMS + V_ELEMS);
   __shared__ __attribute__((aligned(16))) bf16_t lds_all[NG * RING];
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
@@ -165,38 +165,39 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   const float zc = p.clamp > 0.f ? 2.0f * LOG2E * p.scale / p.clamp : p.scale * LOG2E;
   const float c2 = p.clamp * LOG2E;
 
-  // staging registers: K rows (tid>>3)+32i chunk tid&7; V key pair kp = lane&31, d-chunk = 2*wave + (lane>>5).
+  // staging registers: rows (tid>>3)+32i, 16-B chunk tid&7 of the K tile and of the V tile (same geometry, same LDS image).
   // Two register sets: tile jt+2 is requested while tile jt is computed and tile jt+1 (requested one
   // iteration earlier) is written to the other LDS buffer, so a global load has two iterations to land.
   bf16x8 kregA[2], vregA[2], kregB[2], vregB[2];
   const int kchunk = tid & 7, krow = tid >> 3;
-  const int kp = lane & 31, dch = wave * 2 + (lane >> 5);
   auto load_tile = [&](int j0, bf16x8 (&kreg)[2], bf16x8 (&vreg)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key = j0 + krow + 32 * i;
       key = key < p.Nk ? key : p.Nk - 1;
       kreg[i] = *reinterpret_cast<const bf16x8*>(Kg + (int64_t)key * p.krs + kchunk * 8);
-      int vk = j0 + 2 * kp + i;
-      vk = vk < p.Nk ? vk : p.Nk - 1;
-      vreg[i] = *reinterpret_cast<const bf16x8*>(Vg + (int64_t)vk * p.vrs + dch * 8);
+      vreg[i] = *reinterpret_cast<const bf16x8*>(Vg + (int64_t)key * p.vrs + kchunk * 8);
     }
   };
   auto store_tile = [&](bf16_t* base, const bf16x8 (&kreg)[2], const bf16x8 (&vreg)[2]) {
-    bf16_t* ks = base;
-    bf16_t* vt = base + K_ELEMS;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = krow + 32 * i;
-      *reinterpret_cast<bf16x8*>(ks + row * 64 + ((kchunk ^ (row & 7)) << 3)) = kreg[i];
+      const int off = row * 64 + ((kchunk ^ (row & 7)) << 3);
+      *reinterpret_cast<bf16x8*>(base + off) = kreg[i];
+      *reinterpret_cast<bf16x8*>(base + K_ELEMS + off) = vreg[i];
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      bf16x2 pr;
-      pr[0] = vreg[0][i];
-      pr[1] = vreg[1][i];
-      *reinterpret_cast<bf16x2*>(vt + (dch * 8 + i) * VLD + 2 * kp) = pr;
-    }
+  };
+  // V^T fragments by the transposed LDS read (ds_read_b64_tr_b16): per 16-lane group a block of 4 keys x 16 head dimensions,
+  // lane 4q+p of the group supplies the address of (key q, dimensions 4p..4p+3), lane i receives dimension i of the 4 keys --
+  // the [d][4 consecutive keys] operand of O^T = V^T P^T straight from the row-major image (the round-1 kernel transposed V
+  // on its way into LDS with eight 4-byte writes per thread and tile).  EXEC is all ones wherever this is read.
+  const int vq = lr >> 2, vp = lr & 3;
+  auto vt_read = [&](const bf16_t* vs, int key0, int dt) {
+    const int key = key0 + 4 * g + vq;
+    const int chunk = 2 * dt + (vp >> 1);
+    const bf16_t* ad = vs + key * 64 + ((chunk ^ (key & 7)) << 3) + 4 * (vp & 1);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)ad);
   };
 
   const int ntiles_all = (kvn + TK - 1) / TK;
@@ -307,11 +308,10 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
     // ---- O^T += V^T P^T : 4 d tiles x 2 k-steps of 32 keys (permuted key order, see header)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const bf16_t* vrow = vt + (16 * dt + lr) * VLD + 4 * g;
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + 32 * ks2);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32 * ks2 + 16);
+        const bf16x4 lo = vt_read(vt, 32 * ks2, dt);
+        const bf16x4 hi = vt_read(vt, 32 * ks2 + 16, dt);
         bf16x8 vf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -392,8 +392,8 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
 
 template <int NG, int CLAMP>
 __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p) {
-  constexpr int TK = 64, VLD = 68;
-  constexpr int K_ELEMS = TK * 64, V_ELEMS = 64 * VLD;
+  constexpr int TK = 64;
+  constexpr int K_ELEMS = TK * 64, V_ELEMS = TK * 64;     // all four planes row-major [key][64], swizzled like the bf16 kernel's
   constexpr int STAGE = 2 * (K_ELEMS + V_ELEMS);          // Kh | Kl | Vh | Vl
   constexpr int RING = 2 * STAGE;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];
@@ -433,7 +433,6 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
   };
   Raw kregA[2], vregA[2], kregB[2], vregB[2];
   const int kchunk = tid & 7, krow = tid >> 3;
-  const int kp = lane & 31, dch = wave * 2 + (lane >> 5);
   auto load_tile = [&](int j0, Raw (&kreg)[2], Raw (&vreg)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -442,40 +441,32 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
       const float* kpz = Kg + (int64_t)key * p.krs + kchunk * 8;
       kreg[i].a = *reinterpret_cast<const f32x4*>(kpz);
       kreg[i].b = *reinterpret_cast<const f32x4*>(kpz + 4);
-      int vk = j0 + 2 * kp + i;
-      vk = vk < p.Nk ? vk : p.Nk - 1;
-      const float* vpz = Vg + (int64_t)vk * p.vrs + dch * 8;
+      const float* vpz = Vg + (int64_t)key * p.vrs + kchunk * 8;
       vreg[i].a = *reinterpret_cast<const f32x4*>(vpz);
       vreg[i].b = *reinterpret_cast<const f32x4*>(vpz + 4);
     }
   };
   auto store_tile = [&](bf16_t* base, const Raw (&kreg)[2], const Raw (&vreg)[2]) {
-    bf16_t* ksh = base;
-    bf16_t* ksl = base + K_ELEMS;
-    bf16_t* vth = base + 2 * K_ELEMS;
-    bf16_t* vtl = vth + V_ELEMS;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = krow + 32 * i;
+      const int off = row * 64 + ((kchunk ^ (row & 7)) << 3);
       bf16x8 hi, lo;
       split8(kreg[i].a, kreg[i].b, hi, lo);
-      const int off = row * 64 + ((kchunk ^ (row & 7)) << 3);
-      *reinterpret_cast<bf16x8*>(ksh + off) = hi;
-      *reinterpret_cast<bf16x8*>(ksl + off) = lo;
+      *reinterpret_cast<bf16x8*>(base + off) = hi;
+      *reinterpret_cast<bf16x8*>(base + K_ELEMS + off) = lo;
+      split8(vreg[i].a, vreg[i].b, hi, lo);
+      *reinterpret_cast<bf16x8*>(base + 2 * K_ELEMS + off) = hi;
+      *reinterpret_cast<bf16x8*>(base + 2 * K_ELEMS + V_ELEMS + off) = lo;
     }
-    bf16x8 h0, l0, h1, l1;
-    split8(vreg[0].a, vreg[0].b, h0, l0);
-    split8(vreg[1].a, vreg[1].b, h1, l1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      bf16x2 ph, pl;
-      ph[0] = h0[i];
-      ph[1] = h1[i];
-      pl[0] = l0[i];
-      pl[1] = l1[i];
-      *reinterpret_cast<bf16x2*>(vth + (dch * 8 + i) * VLD + 2 * kp) = ph;
-      *reinterpret_cast<bf16x2*>(vtl + (dch * 8 + i) * VLD + 2 * kp) = pl;
-    }
+  };
+  // V^T fragments by ds_read_b64_tr_b16 from the row-major planes (see attn_mfma_kernel)
+  const int vq = lr >> 2, vp = lr & 3;
+  auto vt_read = [&](const bf16_t* vs, int key0, int dt) {
+    const int key = key0 + 4 * g + vq;
+    const int chunk = 2 * dt + (vp >> 1);
+    const bf16_t* ad = vs + key * 64 + ((chunk ^ (key & 7)) << 3) + 4 * (vp & 1);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)ad);
   };
 
   const int ntiles_all = (kvn + TK - 1) / TK;
@@ -588,15 +579,12 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
     // ---- O^T += V^T P^T in three passes
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const int voff = (16 * dt + lr) * VLD + 4 * g;
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
         bf16x8 vfh, vfl;
         {
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vth + voff + 32 * ks2);
-          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vth + voff + 32 * ks2 + 16);
-          const bf16x4 lo2 = *reinterpret_cast<const bf16x4*>(vtl + voff + 32 * ks2);
-          const bf16x4 hi2 = *reinterpret_cast<const bf16x4*>(vtl + voff + 32 * ks2 + 16);
+          const bf16x4 lo = vt_read(vth, 32 * ks2, dt), hi = vt_read(vth, 32 * ks2 + 16, dt);
+          const bf16x4 lo2 = vt_read(vtl, 32 * ks2, dt), hi2 = vt_read(vtl, 32 * ks2 + 16, dt);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             vfh[j] = lo[j];
@@ -891,7 +879,7 @@ void launch_attn_f32(const AttnParams& p, dim3 grid, hipStream_t s) {
 
 template <int NG, int CLAMP>
 void launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
-  constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 68) * sizeof(bf16_t);
+  constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 64) * sizeof(bf16_t);
   auto kern = attn_mfma_split_kernel<NG, CLAMP>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   (void)attr;
