@@ -166,9 +166,9 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   const float c2 = p.clamp * LOG2E;
 
   // staging registers: rows (tid>>3)+32i, 16-B chunk tid&7 of the K tile and of the V tile (same geometry, same LDS image).
-  // Two register sets: tile jt+2 is requested while tile jt is computed and tile jt+1 (requested one
-  // iteration earlier) is written to the other LDS buffer, so a global load has two iterations to land.
-  bf16x8 kregA[2], vregA[2], kregB[2], vregB[2];
+  // One register set: right after the barrier that ends iteration jt-1, tile jt+1 (requested a whole iteration earlier) is
+  // written to the LDS buffer that iteration just stopped reading and tile jt+2 is requested into the same registers.
+  bf16x8 kregA[2], vregA[2];
   const int kchunk = tid & 7, krow = tid >> 3;
   auto load_tile = [&](int j0, bf16x8 (&kreg)[2], bf16x8 (&vreg)[2]) {
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
     load_tile(grp * TK, kregA, vregA);
     store_tile(lds, kregA, vregA);
   }
-  if (ntiles > 1) load_tile((NG + grp) * TK, kregA, vregA);   // local tile 1 -> set A (odd local tiles in A, even >= 2 in B)
+  if (ntiles > 1) load_tile((NG + grp) * TK, kregA, vregA);
   __syncthreads();
   for (int jt = 0; jt < nit; ++jt) {
     if (jt >= ntiles) {          // this group ran out of tiles: keep the block's barrier count
@@ -216,10 +216,8 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
     }
     const bf16_t* ks = lds + (jt & 1) * (K_ELEMS + V_ELEMS);
     const bf16_t* vt = ks + K_ELEMS;
-    if (jt + 2 < ntiles) {
-      if (jt & 1) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
-      else load_tile(((jt + 2) * NG + grp) * TK, kregB, vregB);
-    }
+    if (jt + 1 < ntiles) store_tile(lds + ((jt + 1) & 1) * (K_ELEMS + V_ELEMS), kregA, vregA);
+    if (jt + 2 < ntiles) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
     // ---- S^T = K Q^T : 4 key tiles x 2 k-steps
     f32x4 s[4];
 #pragma unroll
@@ -320,11 +318,6 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
         }
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks2], o[dt], 0, 0, 0);
       }
-    }
-    if (jt + 1 < ntiles) {      // tile jt+1 was requested one iteration ago: odd tiles sit in set A, even in set B
-      bf16_t* nb = lds + ((jt + 1) & 1) * (K_ELEMS + V_ELEMS);
-      if ((jt + 1) & 1) store_tile(nb, kregA, vregA);
-      else store_tile(nb, kregB, vregB);
     }
     __syncthreads();
   }
@@ -431,7 +424,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
   struct Raw {
     f32x4 a, b;
   };
-  Raw kregA[2], vregA[2], kregB[2], vregB[2];
+  Raw kregA[2], vregA[2];       // one set: written to LDS right after the barrier, re-requested at once (see attn_mfma_kernel)
   const int kchunk = tid & 7, krow = tid >> 3;
   auto load_tile = [&](int j0, Raw (&kreg)[2], Raw (&vreg)[2]) {
 #pragma unroll
@@ -487,10 +480,8 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
     const bf16_t* ksl = ksh + K_ELEMS;
     const bf16_t* vth = ksh + 2 * K_ELEMS;
     const bf16_t* vtl = vth + V_ELEMS;
-    if (jt + 2 < ntiles) {
-      if (jt & 1) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
-      else load_tile(((jt + 2) * NG + grp) * TK, kregB, vregB);
-    }
+    if (jt + 1 < ntiles) store_tile(lds + ((jt + 1) & 1) * STAGE, kregA, vregA);
+    if (jt + 2 < ntiles) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
     // ---- S^T = K Q^T in three passes
     f32x4 s[4];
 #pragma unroll
@@ -598,11 +589,6 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, pfh[ks2], o[dt], 0, 0, 0);
       }
     }
-    if (jt + 1 < ntiles) {
-      bf16_t* nb = lds + ((jt + 1) & 1) * STAGE;
-      if ((jt + 1) & 1) store_tile(nb, kregA, vregA);
-      else store_tile(nb, kregB, vregB);
-    }
     __syncthreads();
   }
   l += __shfl_xor(l, 16, 64);
@@ -684,7 +670,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_f32_kernel(AttnParams p) {
   struct Raw {
     f32x4 a, b;
   };
-  Raw kregA[2], vregA[2], kregB[2], vregB[2];
+  Raw kregA[2], vregA[2];       // one set: written to LDS right after the barrier, re-requested at once (see attn_mfma_kernel)
   const int kchunk = tid & 7, krow = tid >> 3;
   const int kp = lane & 31, dch = wave * 2 + (lane >> 5);
   auto load_tile = [&](int j0, Raw (&kreg)[2], Raw (&vreg)[2]) {
@@ -736,10 +722,8 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_f32_kernel(AttnParams p) {
     }
     const float* ks = lds + (jt & 1) * STAGE;
     const float* vt = ks + T_ELEMS;
-    if (jt + 2 < ntiles) {
-      if (jt & 1) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
-      else load_tile(((jt + 2) * NG + grp) * TK, kregB, vregB);
-    }
+    if (jt + 1 < ntiles) store_tile(lds + ((jt + 1) & 1) * STAGE, kregA, vregA);
+    if (jt + 2 < ntiles) load_tile(((jt + 2) * NG + grp) * TK, kregA, vregA);
     // ---- S^T = K Q^T : 4 key tiles x 16 k-steps of 4 head dimensions
     f32x4 s[4];
 #pragma unroll
@@ -824,11 +808,6 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_f32_kernel(AttnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[j], s[t][j], o[dt], 0, 0, 0);
       }
-    }
-    if (jt + 1 < ntiles) {
-      float* nb = lds + ((jt + 1) & 1) * STAGE;
-      if ((jt + 1) & 1) store_tile(nb, kregA, vregA);
-      else store_tile(nb, kregB, vregB);
     }
     __syncthreads();
   }
