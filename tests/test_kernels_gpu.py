@@ -355,12 +355,14 @@ def _attn_ref(q, k, v, gate, kv_len, q_len, clamp=50.0):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, "split"])
 @pytest.mark.parametrize("B,H,Nq,Nk,kv_len,q_len", [(2, 2, 44, 44, [44, 30], [44, 30]), (1, 16, 782, 782, [782], [782]),
-                                                  (2, 3, 100, 5, [5, 3], [100, 70]), (1, 1, 65, 129, [129], [65])])
+                                                  (2, 3, 100, 5, [5, 3], [100, 70]), (1, 1, 65, 129, [129], [65]),
+                                                  (24, 16, 260, 200, [200, 130, 65, 1] * 6, [260, 200, 64, 259] * 6)])
 @pytest.mark.parametrize("clamp", [50.0, 80.0])
 def test_attention(L, dt, B, H, Nq, Nk, kv_len, q_len, clamp):
     """clamp 50 (the reference's value): the bf16 kernel runs without a running maximum (bounded weights); clamp 80: with
     the online maximum (2^(80 log2 e) is too close to fp32's range to skip it).  dt "split": fp32 tensors, products as
-    three bf16 MFMA passes over hi | lo planes (the bf16x3 mode's kernel), held to 2e-4."""
+    three bf16 MFMA passes over hi | lo planes (the bf16x3 mode's kernel), held to 2e-4.  The last shape has 1920 workgroups:
+    the bf16 kernel then runs one wave group per workgroup over all key tiles."""
     code = None
     if dt == "split":
         dt, code = torch.float32, L.BF16_SPLIT
