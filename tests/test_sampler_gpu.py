@@ -271,3 +271,33 @@ def test_many_models_and_plans_keep_their_streams_apart(small):
         assert m.engine().plan["st"] is st[0] and m.engine().plan["sf"] is st[1]
         ref = a if ref is None else ref
         assert torch.equal(a, ref)
+
+
+@pytest.mark.parametrize("case", ["full", "ragged", "dropprompt", "per_sample_times"])
+def test_bf16_folded_norms_match_separate_norm_kernels(small, golden, case):
+    """bf16 mode with the RMSNorms folded into the conv / GEMM epilogues (default) against the same mode with the separate
+    norm kernel (`engine().fold_norm = False`): the two differ only in where the bf16 rounding of the GEMM operand sits
+    (x * gamma rounded, 1/rms applied after the product, vs x * gamma / rms rounded), so they agree to bf16 noise -- through
+    ragged lengths (masked rows), a dropped prompt, the CFG switch row (null half takes the feed-forward norm's gamma from
+    the self-attention epilogue) and per-sample time tables (gamma indexed by batch instead of by step)."""
+    i = small["inp"]
+    outs = []
+    for fold in (True, False):
+        m = make_model(small["cfg"], small["P"], "bf16")
+        m.engine().fold_norm = fold
+        if case == "per_sample_times":
+            o = m.transformer_with_pred_head(i["y0"], times=torch.tensor([0.1, 0.8]), text=i["text"], frames_embed=i["roll"],
+                                             context=i["ctx"], context_mask=i["ctx_mask"], drop_text_cond=False, drop_text_prompt=False)
+        else:
+            kw = dict(steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False, return_raw_output=True)
+            if case == "ragged":
+                kw.update(lens=torch.tensor([40, 29]), duration=torch.tensor([40, 29]))
+            if case == "dropprompt":
+                kw.update(video_drop_prompt=[False, True])
+            o = m.sample(torch.zeros(2, 40, small["cfg"].num_channels), y0=i["y0"], text_embed=i["text"], context=i["ctx"],
+                         context_mask=i["ctx_mask"], frames_embed=i["roll"], **kw)
+        assert bool(torch.isfinite(o).all())
+        outs.append(o.float().cpu())
+    d = (outs[0] - outs[1]).abs()
+    print(f"bf16 folded vs separate norms [{case}]: max {float(d.max()):.4f} mean {float(d.mean()):.5f} (|y| max {float(outs[1].abs().max()):.2f})")
+    assert float(d.mean()) < 0.02 and float(d.max()) < 0.3
