@@ -79,6 +79,11 @@ for s in "$@"; do
            f=""; [ $v = nofold ] && f="--no-fold-norm"
            TAILN=0 run ft_$v 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity-mode --no-configs --no-video2roll --no-vocoder $f
          done ;;
+    sidetiles) for v in ${ST_SWEEP:-"_" "t.qkv=1" "t.ff1=1" "f.cross=1,f.out=1,f.ff2=1" "f.cross=3,f.out=3,f.ff2=3" "_"}; do
+           a=""; [ "$v" != "_" ] && a="--side-tiles $v"
+           TAILN=0 run st_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a
+           echo "--- side tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/st_x.log | head -1)"
+         done ;;
     maintile) SW="${MAIN_SWEEP:--1 1 2 7}"
          for v in $SW; do
            TAILN=0 run mt_$v 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --main-tile $v

@@ -233,6 +233,10 @@ class DiTEngine:
         # audio block on side streams -- few fat workgroups that own whole CUs disturb the critical path less than many small
         # ones spread over every CU (+3.5 % end to end); -1 = the library's stand-alone choice
         self.side_tile = 0 if multi_stream else -1
+        # per-(stream, op) exceptions to the fat-tile policy.  The text stream is co-critical with the audio stream (its block
+        # plus its cross-condition GEMM must fit inside one audio layer): its three 1280-wide GEMMs have only 65 tiles of
+        # 128x256 (FF2: 77 us alone) -- on 128x128 tiles (130 workgroups) the sampler is 3.5 % faster at one clip.
+        self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1}
         self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
@@ -445,11 +449,14 @@ class DiTEngine:
             L.split_bf16(h1, ffh, rows=rows, d=Fw.inner)
         self._mm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, bias=Fw.b2, resid=x, ldo=d, ldr=d, out_bf16=self._sh(x), **out_kw)
 
-    def _side_hint(self):
-        """tile_hint of the text / frames GEMMs: the fat-tile policy only while one launch cannot fill the chip anyway (up to
+    def _side_hint(self, stream="t", op="qkv"):
+        """tile_hint of a text / frames GEMM (op: cross, qkv, out, ff1, ff2) while one launch cannot fill the chip anyway (up to
         two clips: M <= 3128 rows); with more rows every kernel fills all CUs and the library's stand-alone choice is faster
-        (8 clips: text feed-forward 325 us on the 256x256 kernel against 556 us on forced 128x256 tiles)."""
-        return self.side_tile + 1 if (self.side_tile >= 0 and self.plan["rows"] <= 3200) else 0
+        (8 clips: text feed-forward 325 us on the 256x256 kernel against 556 us on forced 128x256 tiles).  `side_tiles` maps
+        (stream, op) to a tile configuration of v2a_tuning.gemm_force_tile; missing entries take `side_tile`."""
+        if self.side_tile < 0 or self.plan["rows"] > 3200:
+            return 0
+        return self.side_tiles.get((stream, op), self.side_tile) + 1
 
     def _main_hint(self):
         return dict(tile_hint=self.main_tile + 1) if (self.main_tile >= 0 and self.plan["rows"] <= 3200) else {}
@@ -462,11 +469,12 @@ class DiTEngine:
         N, rows = p["N"], nseq * p["N"]
         lens = p["seq_len"] if p["ragged"] else None
         cv = ly[f"{s}_conv"]
-        hint = dict(tile_hint=self._side_hint())
+        hq, ho, h1, h2 = (dict(tile_hint=self._side_hint(s, op)) for op in ("qkv", "out", "ff1", "ff2"))
         fold, fold2 = self._fold(), self._fold_gemm()
         hn, ssq = p[f"hn_{s}"], p[f"ssq_{s}"]
-        cons = dict(**hint, **self._ncons(s, d))
-        cons2 = cons if fold2 else hint
+        nc = self._ncons(s, d)
+        cons = dict(**hq, **nc)
+        cons2 = dict(**h1, **(nc if fold2 else {}))
         if 0 in parts:
             if fold:
                 L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens,
@@ -476,11 +484,11 @@ class DiTEngine:
                 self._norm_plain(dst, hn, rows, d, ly[f"{s}_g1"])
         if 1 in parts:
             prod = dict(out_bf16=hn, ld_out_bf16=d, norm_gamma=ly[f"{s}_g2"], norm_ssq=ssq) if fold2 else {}
-            self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint, **prod), cons)
+            self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **ho, **prod), cons)
         if 2 in parts:
             if not fold2:
                 self._norm_plain(dst, hn, rows, d, ly[f"{s}_g2"])
-            self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **hint), cons2)
+            self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **h2), cons2)
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
@@ -649,10 +657,12 @@ class DiTEngine:
                      epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn), **mh)
             if not last:
                 nxt = W.layers[i + 1]
-                hint = self._side_hint() if (multi and not self.cross_on_main) else 0
+                on_side = multi and not self.cross_on_main
+                hint_t = self._side_hint("t", "cross") if on_side else 0
+                hint = self._side_hint("f", "cross") if on_side else 0
                 def cross_t():
                     self._mm([(ax, D, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt,
-                             epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt, tile_hint=hint)
+                             epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt, tile_hint=hint_t)
                 def cross_f():
                     self._mm([(ax, D, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df,
                              epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df, tile_hint=hint)
