@@ -81,7 +81,7 @@ for s in "$@"; do
          done ;;
     sidetiles) for v in ${ST_SWEEP:-"_" "t.qkv=1" "t.ff1=1" "f.cross=1,f.out=1,f.ff2=1" "f.cross=3,f.out=3,f.ff2=3" "_"}; do
            a=""; [ "$v" != "_" ] && a="--side-tiles $v"
-           TAILN=0 run st_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a
+           TAILN=0 run st_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${ST_EXTRA:-}
            echo "--- side tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/st_x.log | head -1)"
          done ;;
     maintile) SW="${MAIN_SWEEP:--1 1 2 7}"

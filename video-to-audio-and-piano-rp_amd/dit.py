@@ -236,7 +236,12 @@ class DiTEngine:
         # per-(stream, op) exceptions to the fat-tile policy.  The text stream is co-critical with the audio stream (its block
         # plus its cross-condition GEMM must fit inside one audio layer): its three 1280-wide GEMMs have only 65 tiles of
         # 128x256 (FF2: 77 us alone) -- on 128x128 tiles (130 workgroups) the sampler is 3.5 % faster at one clip.
-        self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1}
+        # ... and its feed-forward GEMM (N = 10240: 7 x 40 tiles of 256x256) on the phase-interleaved kernel: another 1.5 %.
+        # ("a", op) entries apply to the audio stream's GEMMs (ops: x_tfa skip qkv out q2 out2 ff1 ff2): its feed-forward
+        # GEMM on the phase-interleaved kernel too (+2 %), its QKV GEMM on 128x128 tiles (+0.4 %); frames feed-forward on the
+        # phase-interleaved kernel (+0.6 %).  Each entry A/B-ed alone and in combination on one box (bench.py --side-tiles).
+        self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
+                           ("f", "ff1"): 6}
         self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
@@ -458,8 +463,11 @@ class DiTEngine:
             return 0
         return self.side_tiles.get((stream, op), self.side_tile) + 1
 
-    def _main_hint(self):
-        return dict(tile_hint=self.main_tile + 1) if (self.main_tile >= 0 and self.plan["rows"] <= 3200) else {}
+    def _main_hint(self, op=None):
+        if self.plan["rows"] > 3200:
+            return {}
+        t = self.side_tiles.get(("a", op), self.main_tile if op in ("x_tfa", "skip", "out", "out2", "ff2") else -1)
+        return dict(tile_hint=t + 1) if t >= 0 else {}
 
     def _side_block(self, ly, s, src, dst, nseq, d, parts=(0, 1, 2)):
         """text / frames stream block (x3:1081-1086, 1097-1101): conv, attention, feed-forward.  `parts` selects
@@ -652,9 +660,9 @@ class DiTEngine:
             wait(main, eT, eF)
             xn = p["skips"][i] if i < half else xo
             ax, at_, af_ = self._opnd(xc), self._opnd(tc_), self._opnd(fc_)
-            mh = self._main_hint()
+            mh = self._main_hint
             self._mm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D,
-                     epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn), **mh)
+                     epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn), **mh("x_tfa"))
             if not last:
                 nxt = W.layers[i + 1]
                 on_side = multi and not self.cross_on_main
@@ -685,7 +693,7 @@ class DiTEngine:
                 src = xn
             else:
                 src = p["xS"]
-                self._mm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src, M=rows, N=D, ldo=D, **mh)
+                self._mm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src, M=rows, N=D, ldo=D, **mh("skip"))
             dst = xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
@@ -709,7 +717,7 @@ class DiTEngine:
                 n1 = self._nprod_ada(i, 1, switch_row=r2 if r2 < rows else 0) if nctx > 0 else self._nprod_ada(i, 2)
                 n1 = {k: v for k, v in n1.items() if k not in ("step", "rows_per_batch")}       # the gate already passes them
                 prod1 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n1)
-            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), **mh, **prod1), cons)
+            self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), **mh("out"), **prod1), dict(**cons, **mh("qkv")))
             if not last and self.interleave_capture:
                 for part in (0, 1):
                     with _On(st):
@@ -727,9 +735,9 @@ class DiTEngine:
                 q2 = p["q2"]
                 if self.rope_cross and self._fuse_rope:
                     self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad,
-                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons2)
+                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons2, **mh("q2"))
                 else:
-                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad, **cons2)
+                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad, **cons2, **mh("q2"))
                     if self.rope_cross:
                         L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
                                table=p["rope"], layout=self.rope_layout)
@@ -750,10 +758,10 @@ class DiTEngine:
                     n2 = {k: v for k, v in self._nprod_ada(i, 2).items() if k not in ("step", "rows_per_batch")}
                     prod2 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n2)
                 self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
-                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh, **prod2)
+                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh("out2"), **prod2)
             if not fold2:
                 self._norm_ada(x, p["hn_a"], rows, D, i, 2)
-            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh), cons2)
+            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh("ff2")), dict(**cons2, **mh("ff1")))
             if not last:
                 if not self.cross_on_main:
                     eA = rec(main)             # x of the next layer is ready
