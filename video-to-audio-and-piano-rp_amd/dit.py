@@ -461,10 +461,12 @@ class DiTEngine:
         (stream, op) to a tile configuration of v2a_tuning.gemm_force_tile; missing entries take `side_tile`."""
         if self.side_tile < 0 or self.plan["rows"] > 3200:
             return 0
+        if self.plan["rows"] > 1600:        # two clips: the table below was tuned at one clip and costs 4 % here (6214 vs 6467)
+            return self.side_tile + 1
         return self.side_tiles.get((stream, op), self.side_tile) + 1
 
     def _main_hint(self, op=None):
-        if self.plan["rows"] > 3200:
+        if self.plan["rows"] > 1600:
             return {}
         t = self.side_tiles.get(("a", op), self.main_tile if op in ("x_tfa", "skip", "out", "out2", "ff2") else -1)
         return dict(tile_hint=t + 1) if t >= 0 else {}
