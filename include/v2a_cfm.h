@@ -151,7 +151,9 @@ typedef struct v2a_tuning {
   int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass, 4 or 6 (0 = default 4) */
   int32_t gemm_xcd_order_1x8;     /* 1: every XCD walks whole column strips of the tile space (the round-1 order) instead of the
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
-  int32_t reserved[2];
+  int32_t attn_one_group_from;    /* v2a_attention (bf16): launches with at least this many workgroups run one wave group per workgroup
+                                   * instead of two that split the key tiles (0 = default 1536) */
+  int32_t reserved[1];
 } v2a_tuning;
 int v2a_set_tuning(const v2a_tuning* tuning);
 

@@ -58,7 +58,7 @@ class Tuning(C.Structure):
     """Mirror of `v2a_tuning` (include/v2a_cfm.h): explicit tile-selection overrides, nothing is read from the environment."""
     _fields_ = [("gemm_force_tile", C.c_int32), ("gemm_k_rotation", C.c_int32), ("gemm_8phase", C.c_int32),
                 ("gemm_8phase_min_tiles", C.c_int32), ("dwconv_rows_per_wave", C.c_int32), ("gemm_xcd_order_1x8", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("attn_one_group_from", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class AttnArgs(C.Structure):
@@ -159,14 +159,14 @@ def lib():
 
 
 def set_tuning(force_tile: int = -1, k_rotation: bool = False, eight_phase: int | None = None, eight_phase_min_tiles: int = 0,
-               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False):
+               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0):
     """Tile-selection overrides (A/B measurements); `set_tuning()` restores the library defaults."""
     if (force_tile == -1 and not k_rotation and eight_phase is None and eight_phase_min_tiles == 0 and dwconv_rows_per_wave == 0
-            and not xcd_order_1x8):
+            and not xcd_order_1x8 and attn_one_group_from == 0):
         check(lib().v2a_set_tuning(None))
         return
     t = Tuning(force_tile, 1 if k_rotation else 0, 1 if eight_phase is None else eight_phase, eight_phase_min_tiles, dwconv_rows_per_wave,
-               1 if xcd_order_1x8 else 0)
+               1 if xcd_order_1x8 else 0, attn_one_group_from)
     check(lib().v2a_set_tuning(C.byref(t)))
 
 

@@ -11,6 +11,8 @@
 //     the softmax row reductions done by wavefront shuffles.
 #include "v2a_common.h"
 
+namespace v2a_detail { extern int g_attn_one_group_from; }
+
 namespace {
 
 struct AttnParams {
@@ -927,7 +929,7 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
     const int cl = a->softclamp > 0.f ? (a->softclamp * 1.4426950408889634f <= 100.f ? 2 : 1) : 0;
     // two wave groups split the key tiles of a workgroup's 64 queries (merged at the end) while the launch is short of
     // workgroups; from ~6 workgroups per CU on, one group per workgroup: no merge, 4-wave barriers
-    const bool split_kv = a->Nk > 128 && (int64_t)g64.x * g64.y * g64.z < 1536;
+    const bool split_kv = a->Nk > 128 && (int64_t)g64.x * g64.y * g64.z < v2a_detail::g_attn_one_group_from;
     if (aligned && split_kv) {
       if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<2, 2>), g64, dim3(512), 0, s, p);
       else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<2, 1>), g64, dim3(512), 0, s, p);

@@ -407,6 +407,7 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400, 1};
 v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
+int v2a_detail::g_attn_one_group_from = 1536;
 
 extern "C" int v2a_gemm_args_size(void) { return (int)sizeof(v2a_gemm_args); }
 
@@ -414,11 +415,13 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   if (!t) {
     v2a_detail::g_gemm_tuning = kDefaultTuning;
     v2a_detail::g_dwconv_rows_per_wave = 4;
+    v2a_detail::g_attn_one_group_from = 1536;
     return V2A_OK;
   }
   V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6, "v2a_set_tuning: dwconv_rows_per_wave %d",
               t->dwconv_rows_per_wave);
   v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave ? t->dwconv_rows_per_wave : 4;
+  v2a_detail::g_attn_one_group_from = t->attn_one_group_from > 0 ? t->attn_one_group_from : 1536;
   V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 8, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
   V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
   v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,

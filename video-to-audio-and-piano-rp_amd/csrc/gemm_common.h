@@ -60,6 +60,7 @@ struct GemmTuning {
   int xcd_grid;          // 1: XCD rectangle grid chosen per shape, 0: always 1 x 8 (every XCD walks all M of its column strip)
 };
 extern GemmTuning g_gemm_tuning;
+extern int g_attn_one_group_from;    // v2a_attention: workgroup count from which one wave group per workgroup is used
 extern int g_dwconv_rows_per_wave;   // 4 or 8 (v2a_set_tuning)
 
 // 256x256 8-phase kernel (gemm_8phase.hip)
