@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--interleave-capture", type=int, default=-1, help="A/B: 1 = interleave the capture order of audio and side blocks")
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
     ap.add_argument("--no-fold-norm", action="store_true", help="A/B: separate RMSNorm launches instead of folding them into the neighbouring kernels")
+    ap.add_argument("--big-tiles", default="", help="A/B: the same table for launches of more than two clips, e.g. a.qkv=0,t.ff2=6")
     ap.add_argument("--side-tiles", default="", help="A/B: per-(stream, op) tile configurations of the side-stream GEMMs, e.g. t.qkv=1,f.ff2=2 (ops: cross qkv out ff1 ff2; -1 = library choice)")
     ap.add_argument("--attn-one-group-from", type=int, default=0, help="A/B: workgroup count from which bf16 attention runs one wave group per workgroup (0 = library default)")
     ap.add_argument("--main-tile", type=int, default=-1, help="A/B: GEMM tile configuration of the audio stream's narrow-output GEMMs (-1 library choice)")
@@ -148,10 +149,11 @@ def main():
         model.engine().side_tile = args.side_tile
     if args.main_tile >= 0:
         model.engine().main_tile = args.main_tile
-    for item in filter(None, args.side_tiles.split(",")):
-        key, val = item.split("=")
-        st_, op_ = key.split(".")
-        model.engine().side_tiles[(st_, op_)] = int(val)
+    for spec, table in ((args.side_tiles, model.engine().side_tiles), (args.big_tiles, model.engine().big_tiles)):
+        for item in filter(None, spec.split(",")):
+            key, val = item.split("=")
+            st_, op_ = key.split(".")
+            table[(st_, op_)] = int(val)
     if args.no_fold_norm:
         model.engine().fold_norm = False
     model.engine().cross_on_main = args.cross_on_main

@@ -84,6 +84,11 @@ for s in "$@"; do
            TAILN=0 run st_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${ST_EXTRA:-}
            echo "--- side tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/st_x.log | head -1)"
          done ;;
+    bigtiles) for v in ${BT_SWEEP:-"_" "a.qkv=0,t.qkv=0" "f.qkv=0" "a.ff2=0" "_"}; do
+           a=""; [ "$v" != "_" ] && a="--big-tiles $v"
+           TAILN=0 run bt_x 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --clips-per-gpu 8 $a
+           echo "--- big tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/bt_x.log | head -1)"
+         done ;;
     maintile) SW="${MAIN_SWEEP:--1 1 2 7}"
          for v in $SW; do
            TAILN=0 run mt_$v 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --main-tile $v

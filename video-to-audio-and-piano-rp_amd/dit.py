@@ -240,6 +240,7 @@ class DiTEngine:
         # ("a", op) entries apply to the audio stream's GEMMs (ops: x_tfa skip qkv out q2 out2 ff1 ff2): its feed-forward
         # GEMM on the phase-interleaved kernel too (+2 %), its QKV GEMM on 128x128 tiles (+0.4 %); frames feed-forward on the
         # phase-interleaved kernel (+0.6 %).  Each entry A/B-ed alone and in combination on one box (bench.py --side-tiles).
+        self.big_tiles = {}             # the same kind of table for launches of more than two clips (default: library choice)
         self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
                            ("f", "ff1"): 6}
         self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
@@ -459,13 +460,18 @@ class DiTEngine:
         two clips: M <= 3128 rows); with more rows every kernel fills all CUs and the library's stand-alone choice is faster
         (8 clips: text feed-forward 325 us on the 256x256 kernel against 556 us on forced 128x256 tiles).  `side_tiles` maps
         (stream, op) to a tile configuration of v2a_tuning.gemm_force_tile; missing entries take `side_tile`."""
-        if self.side_tile < 0 or self.plan["rows"] > 3200:
+        if self.side_tile < 0:
             return 0
+        if self.plan["rows"] > 3200:
+            return self.big_tiles.get((stream, op), -1) + 1
         if self.plan["rows"] > 1600:        # two clips: the table below was tuned at one clip and costs 4 % here (6214 vs 6467)
             return self.side_tile + 1
         return self.side_tiles.get((stream, op), self.side_tile) + 1
 
     def _main_hint(self, op=None):
+        if self.plan["rows"] > 3200:
+            t = self.big_tiles.get(("a", op), -1)
+            return dict(tile_hint=t + 1) if t >= 0 else {}
         if self.plan["rows"] > 1600:
             return {}
         t = self.side_tiles.get(("a", op), self.main_tile if op in ("x_tfa", "skip", "out", "out2", "ff2") else -1)
