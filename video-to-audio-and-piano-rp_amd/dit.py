@@ -239,10 +239,10 @@ class DiTEngine:
         # ... and its feed-forward GEMM (N = 10240: 7 x 40 tiles of 256x256) on the phase-interleaved kernel: another 1.5 %.
         # ("a", op) entries apply to the audio stream's GEMMs (ops: x_tfa skip qkv out q2 out2 ff1 ff2): its feed-forward
         # GEMM on the phase-interleaved kernel too (+2 %), its QKV GEMM on 128x128 tiles (+0.4 %); frames feed-forward on the
-        # phase-interleaved kernel (+0.6 %).  Each entry A/B-ed alone and in combination on one box (bench.py --side-tiles).
+        # phase-interleaved kernel (+0.6 %), frames QKV too (49 tiles: +1.7 %).  Each entry A/B-ed alone and in combination on one box (bench.py --side-tiles).
         self.big_tiles = {}             # the same kind of table for launches of more than two clips (default: library choice)
         self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
-                           ("f", "ff1"): 6}
+                           ("f", "ff1"): 6, ("f", "qkv"): 6}
         self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
