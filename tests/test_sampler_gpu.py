@@ -301,3 +301,28 @@ def test_bf16_folded_norms_match_separate_norm_kernels(small, golden, case):
     d = (outs[0] - outs[1]).abs()
     print(f"bf16 folded vs separate norms [{case}]: max {float(d.max()):.4f} mean {float(d.mean()):.5f} (|y| max {float(outs[1].abs().max()):.2f})")
     assert float(d.mean()) < 0.02 and float(d.max()) < 0.3
+
+
+@pytest.mark.parametrize("case", ["full", "ragged"])
+def test_bf16_fused_cross_condition_and_skip_match_two_gemms(small, golden, case):
+    """bf16 mode, second half of the stack: cross-condition + U-Net skip projection as ONE GEMM over [x | skip | text | frames]
+    with pre-multiplied weights (default) against the two GEMMs of the reference's order (`engine().fuse_skip = False`):
+    identical algebra, different bf16 rounding points (the product Ws_x W1 is rounded once instead of x + W1[...] being
+    rounded between the two GEMMs) -- agreement to bf16 noise, and both within the usual bf16 distance of the fp32 golden."""
+    i, g = small["inp"], golden["sample_small"]
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False, return_raw_output=True)
+    key = "y_full"
+    if case == "ragged":
+        kw.update(lens=torch.tensor([40, 29]), duration=torch.tensor([40, 29]))
+        key = "y_ragged"
+    outs = []
+    for fuse in (True, False):
+        m = make_model(small["cfg"], small["P"], "bf16")
+        m.engine().fuse_skip = fuse
+        o = m.sample(torch.zeros(2, 40, small["cfg"].num_channels), y0=i["y0"], text_embed=i["text"], context=i["ctx"],
+                     context_mask=i["ctx_mask"], frames_embed=i["roll"], **kw)
+        outs.append(o.float().cpu())
+    d = (outs[0] - outs[1]).abs()
+    e = [float((o - torch.from_numpy(g[key])).abs().mean()) for o in outs]
+    print(f"bf16 fused vs two-GEMM skip [{case}]: max {float(d.max()):.4f} mean {float(d.mean()):.5f}; mean |delta| vs fp32 golden {e[0]:.5f} / {e[1]:.5f}")
+    assert float(d.mean()) < 0.02 and float(d.max()) < 0.3 and e[0] < 1.5 * e[1] + 0.01

@@ -165,6 +165,16 @@ class PackedWeights:
             ly = {}
             if i >= c.depth // 2:
                 ly["skip"] = pk(sd[f"{P}.0.0.weight"], [c.dim, c.dim])
+                if cd == torch.bfloat16 and not split:
+                    # cross-condition and U-Net skip of the second half as ONE GEMM (bf16 mode; both Linears are bias-free):
+                    #   skip_proj(cat(x + W1 [x; t; f], s)) = Ws_x (I + W1_a) x + Ws_s s + (Ws_x W1_t) t + (Ws_x W1_f) f
+                    # K = 3840 instead of 2816 + 2048, one launch instead of two on the audio stream's critical path.  Column
+                    # order [x | s | t | f]: x and s are the two halves of one 2048-wide bf16 operand buffer (DiTEngine).
+                    ws = sd[f"{P}.0.0.weight"].double()
+                    w1 = sd[f"{P}.1.5.text_frames_to_audio.weight"].double()
+                    wsx, wss = ws[:, :c.dim], ws[:, c.dim:]
+                    fused = torch.cat([wsx @ w1[:, :c.dim] + wsx, wss, wsx @ w1[:, c.dim:c.dim + c.dim_text], wsx @ w1[:, c.dim + c.dim_text:]], 1)
+                    ly["x_skip"] = pk(fused.float(), [2 * c.dim, c.dim_text, c.dim_frames])
             ly["a_conv"] = _Conv(sd, f"{P}.0.1", dev)
             ly["a_attn"] = _Attn(sd, f"{P}.0.3", c.dim, c.heads, c.dim_head, cd, dev, split=split)
             ly["a_attn2"] = _Attn(sd, f"{P}.0.6", c.dim, c.heads, c.dim_head, cd, dev, cross=True, split=split)
@@ -240,6 +250,7 @@ class DiTEngine:
         # ("a", op) entries apply to the audio stream's GEMMs (ops: x_tfa skip qkv out q2 out2 ff1 ff2): its feed-forward
         # GEMM on the phase-interleaved kernel too (+2 %), its QKV GEMM on 128x128 tiles (+0.4 %); frames feed-forward on the
         # phase-interleaved kernel (+0.6 %), frames QKV too (49 tiles: +1.7 %).  Each entry A/B-ed alone and in combination on one box (bench.py --side-tiles).
+        self.fuse_skip = True           # bf16 mode: cross-condition + skip projection of layers >= depth/2 as one GEMM (PackedWeights)
         self.big_tiles = {}             # the same kind of table for launches of more than two clips (default: library choice)
         self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
                            ("f", "ff1"): 6, ("f", "qkv"): 6}
@@ -308,8 +319,16 @@ class DiTEngine:
             mk = lambda t: torch.empty(*t.shape[:-1], w2 * t.shape[-1], dtype=cd, device=dev)
             for name in ("xA", "xB", "tA", "tB", "tL0", "fA", "fB", "fL0"):
                 p["shadow"][p[name].data_ptr()] = mk(p[name])
-            for sk in p["skips"]:
-                p["shadow"][sk.data_ptr()] = mk(sk)
+            if self.split:
+                for sk in p["skips"]:
+                    p["shadow"][sk.data_ptr()] = mk(sk)
+            else:
+                # [x entering layer depth-1-j | skip j] as one 2048-wide operand buffer per skip: the fused cross-condition +
+                # skip GEMM reads both halves as ONE K segment; the halves are written by the FF2 epilogue of layer
+                # depth-2-j (x's shadow) and by the cross-condition epilogue of layer j (skip j's shadow)
+                p["wide"] = [torch.empty(Bt, N, 2 * D, dtype=cd, device=dev) for _ in p["skips"]]
+                for sk, wd in zip(p["skips"], p["wide"]):
+                    p["shadow"][sk.data_ptr()] = wd[..., D:]
         p["q2"] = e(B * N, W0["a_attn2"].n_pad, dt=self.ad)
         inner = c.heads * c.dim_head
         p["ctx_kv"] = e(B * nc, 2 * c.depth * inner, dt=self.ad)
@@ -356,6 +375,8 @@ class DiTEngine:
         launches after the first accumulate in place (RESID with resid = out), a requested bf16 shadow of the result is
         produced by v2a_split_bf16 afterwards."""
         if not self.split:
+            if kw.get("out_bf16") is not None and "ld_out_bf16" not in kw:
+                kw["ld_out_bf16"] = kw["out_bf16"].stride(-2)        # a shadow may be half of a wider operand buffer
             return L.gemm(segs, W, out, compute=self.cdc, **kw)
         shadow = kw.pop("out_bf16", None)
         for si, (buf, _, k) in enumerate(segs):
@@ -380,6 +401,9 @@ class DiTEngine:
             L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, gamma_batch_stride=ss, rows_per_batch=p["N"], split=self.split)
         else:
             L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, step=p["step"], gamma_step_stride=ss, rows_per_batch=p["N"], split=self.split)
+
+    def _fuse_skip(self):
+        return self.fuse_skip and not self.split and self.cd == torch.bfloat16 and "x_skip" in self.W.layers[-1]
 
     def _fold(self):
         c = self.cfg
@@ -453,7 +477,9 @@ class DiTEngine:
         self._mm([(hn, d, d)], Fw.w1, h1, M=rows, N=2 * Fw.inner, epilogue=L.EPI_GEGLU, bias=Fw.b1, ldo=Fw.inner, **in_kw)
         if self.split:
             L.split_bf16(h1, ffh, rows=rows, d=Fw.inner)
-        self._mm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, bias=Fw.b2, resid=x, ldo=d, ldr=d, out_bf16=self._sh(x), **out_kw)
+        out_kw = dict(out_kw)
+        shadow = out_kw.pop("out_bf16", self._sh(x))         # the audio stream redirects it into a wide operand buffer (forward)
+        self._mm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, bias=Fw.b2, resid=x, ldo=d, ldr=d, out_bf16=shadow, **out_kw)
 
     def _side_hint(self, stream="t", op="qkv"):
         """tile_hint of a text / frames GEMM (op: cross, qkv, out, ff1, ff2) while one launch cannot fill the chip anyway (up to
@@ -623,6 +649,7 @@ class DiTEngine:
         nctx = B if n_ctx_seqs is None else n_ctx_seqs
         lens = p["seq_len"] if p["ragged"] else None
         half = c.depth // 2
+        fz = self._fuse_skip()
         inner = c.heads * c.dim_head
         nkv = 2 * c.depth * inner
         xc, xo = p["xA"], p["xB"]
@@ -669,18 +696,27 @@ class DiTEngine:
             xn = p["skips"][i] if i < half else xo
             ax, at_, af_ = self._opnd(xc), self._opnd(tc_), self._opnd(fc_)
             mh = self._main_hint
-            self._mm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D,
-                     epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn), **mh("x_tfa"))
+            fused = fz and i >= half
+            if fused:
+                # second half, bf16 mode: cross-condition + skip projection in one GEMM over [x | skip | text | frames]; x's
+                # bf16 copy was written into the left half of the skip's wide buffer by the previous layer's FF2 epilogue
+                wd = p["wide"][c.depth - 1 - i]
+                ax = wd[..., :D]
+                self._mm([(wd, 2 * D, 2 * D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_skip"], p["xS"], M=rows, N=D, ldo=D, **mh("x_tfa"))
+            else:
+                self._mm([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D,
+                         epilogue=L.EPI_RESID, resid=xc, ldo=D, ldr=D, out_bf16=self._sh(xn), **mh("x_tfa"))
+            ax_ld = ax.stride(-2)
             if not last:
                 nxt = W.layers[i + 1]
                 on_side = multi and not self.cross_on_main
                 hint_t = self._side_hint("t", "cross") if on_side else 0
                 hint = self._side_hint("f", "cross") if on_side else 0
                 def cross_t():
-                    self._mm([(ax, D, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt,
+                    self._mm([(ax, ax_ld, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt,
                              epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt, tile_hint=hint_t)
                 def cross_f():
-                    self._mm([(ax, D, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df,
+                    self._mm([(ax, ax_ld, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df,
                              epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df, tile_hint=hint)
                 if self.cross_on_main or not multi:
                     cross_t()
@@ -699,9 +735,12 @@ class DiTEngine:
             # skip_proj(cat(x, skip)) -> spare buffer.  The conv output (and the whole audio block after it) goes to xo.
             if i < half:
                 src = xn
+            elif fused:
+                src = p["xS"]
             else:
                 src = p["xS"]
-                self._mm([(self._opnd(xn), D, D), (self._opnd(p["skips"][c.depth - 1 - i]), D, D)], ly["skip"], src, M=rows, N=D, ldo=D, **mh("skip"))
+                sk = self._opnd(p["skips"][c.depth - 1 - i])          # bf16 mode: the right half of a wide operand buffer
+                self._mm([(self._opnd(xn), D, D), (sk, sk.stride(-2), D)], ly["skip"], src, M=rows, N=D, ldo=D, **mh("skip"))
             dst = xo
             # audio stream (x3:1121-1137)
             cv = ly["a_conv"]
@@ -769,7 +808,9 @@ class DiTEngine:
                          epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh("out2"), **prod2)
             if not fold2:
                 self._norm_ada(x, p["hn_a"], rows, D, i, 2)
-            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh("ff2")), dict(**cons2, **mh("ff1")))
+            # the bf16 copy of this layer's output: into the wide buffer of the next layer's skip when that layer is fused
+            xsh = dict(out_bf16=p["wide"][c.depth - 2 - i][..., :D]) if (fz and half <= i + 1 < c.depth) else {}
+            self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh("ff2"), **xsh), dict(**cons2, **mh("ff1")))
             if not last:
                 if not self.cross_on_main:
                     eA = rec(main)             # x of the next layer is ready
