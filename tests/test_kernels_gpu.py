@@ -786,3 +786,37 @@ def test_folded_norm_chain_equals_norm_then_linear(L):
     e_ref, e_got = float((ref - exact).abs().max()), float((got - exact).abs().max())
     print(f"norm -> linear vs fp32: separate kernels {e_ref:.3e}, folded {e_got:.3e}")
     assert e_got < 1.5 * e_ref + 1e-3
+
+
+@pytest.mark.parametrize("hint", [1, 2, 7])
+@pytest.mark.parametrize("ks", [(512, 512, 512), (1024, 1280, 512), (64, 128, 64)])
+def test_gemm_tile_hint_three_segments_bitwise(L, hint, ks):
+    """Three K-concatenated segments (the cross-condition GEMMs; every bf16x3 GEMM): 128x256 / 128x128 ring tiles and the
+    256x256 phase-interleaved kernel give bit for bit what 64x64 tiles give -- segment switches do not reorder the K sum."""
+    M, N = 1564, 1552
+    g = _g(hint + sum(ks))
+    segs = [torch.randn(M, k, generator=g).bfloat16().to(DEV) for k in ks]
+    K = sum(ks)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    ref, got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    a = [(t, k, k) for t, k in zip(segs, ks)]
+    L.gemm(a, w, ref, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, resid=resid, tile_hint=4)
+    L.gemm(a, w, got, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, resid=resid, tile_hint=hint)
+    assert torch.equal(got, ref)
+    # the bf16x3 QKV call: [A_hi | A_hi | A_lo] planes of ONE buffer as the three segments (row stride 2k), fp32 STORE + bias
+    k = ks[0]
+    planes = torch.randn(M, 2 * k, generator=g).bfloat16().to(DEV)
+    w3 = (torch.randn(N, 3 * k, generator=g) / math.sqrt(3 * k)).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    a3 = [(planes, 2 * k, k), (planes, 2 * k, k), (planes[:, k:], 2 * k, k)]
+    L.gemm(a3, w3, ref, M=M, N=N, compute=L.BF16, bias=bias, tile_hint=4)
+    L.gemm(a3, w3, got, M=M, N=N, compute=L.BF16, bias=bias, tile_hint=hint)
+    assert torch.equal(got, ref)
+    # ... with the rotary embedding fused into the epilogue (fp32 output): the rotation is written with explicit fused
+    # multiply-adds so that every instantiation rounds it the same way
+    tab = _rope_table(782).to(DEV)
+    kw = dict(M=M, N=N, compute=L.BF16, bias=bias, rope_table=tab, rope_cols=1024, rope_pos_offset=0, rows_per_batch=782)
+    L.gemm(a3, w3, ref, tile_hint=4, **kw)
+    L.gemm(a3, w3, got, tile_hint=hint, **kw)
+    assert torch.equal(got, ref)

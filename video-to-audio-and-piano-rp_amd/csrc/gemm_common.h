@@ -432,10 +432,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
             if constexpr (PF) cs = pf.cs[i][q];
             else cs = *reinterpret_cast<const f32x4*>(p.rope + ((int64_t)(p.rope_pos_off + m % p.rpb) * 32 + ((n & 63) >> 1)) * 2);
             const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
-            v[0] = a0 * cs[0] - b0 * cs[1];
-            v[1] = b0 * cs[0] + a0 * cs[1];
-            v[2] = a1 * cs[2] - b1 * cs[3];
-            v[3] = b1 * cs[2] + a1 * cs[3];
+            // one fixed contraction: left to -ffp-contract the two kernels' instantiations picked different multiply-add
+            // pairings and the rotated columns differed in the last bit between tile shapes
+            v[0] = fmaf(a0, cs[0], -(b0 * cs[1]));
+            v[1] = fmaf(b0, cs[0], a0 * cs[1]);
+            v[2] = fmaf(a1, cs[2], -(b1 * cs[3]));
+            v[3] = fmaf(b1, cs[2], a1 * cs[3]);
           }
         }
         if constexpr (EPI == V2A_EPI_RESID || EPI == V2A_EPI_GATE_RESID) {
