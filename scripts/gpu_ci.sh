@@ -89,9 +89,9 @@ for s in "$@"; do
            TAILN=0 run bt_x 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --clips-per-gpu 8 $a
            echo "--- big tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/bt_x.log | head -1)"
          done ;;
-    misc1) for v in "" "--interleave-capture 1" "--side-tiles t.qkv=6" "--side-tiles a.qkv=6" "--side-tiles f.ff2=6,f.out=6,f.cross=6" "--side-tiles f.ff2=1,f.out=1,f.cross=1" ""; do
-           TAILN=0 run m1_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $v
-           echo "--- [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/m1_x.log | head -1)"
+    misc1) for v in "" "--interleave-capture 1" "" "--interleave-capture 1" "" "--interleave-capture 1"; do
+           TAILN=0 run m1_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v
+           echo "--- [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/m1_x.log | head -1) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/m1_x.log | head -1)"
          done ;;
     maintile) SW="${MAIN_SWEEP:--1 1 2 7}"
          for v in $SW; do
