@@ -93,6 +93,15 @@ for s in "$@"; do
            TAILN=0 run m1_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v
            echo "--- [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/m1_x.log | head -1) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/m1_x.log | head -1)"
          done ;;
+    x3tiles) for v in "_" "t.cross=0,t.out=0,t.ff2=0,t.ff1=0,a.ff1=-1,a.qkv=-1,f.ff1=0,f.qkv=0" "t.ff1=0,a.ff1=-1,f.ff1=0,f.qkv=0" "a.qkv=-1" "_"; do
+           a=""; [ "$v" != "_" ] && a="--side-tiles $v"
+           TAILN=0 run x3_x 300 python bench.py --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a
+           echo "--- bf16x3 side tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/x3_x.log | head -1)"
+         done ;;
+    prof_modes) for m in bf16x3 fp32; do
+           rm -rf /tmp/profm; run prof_$m 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profm -- python bench.py --dtype $m --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+           mkdir -p gpurun_out/prof; cp /tmp/profm/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_$m.csv
+         done ;;
     maintile) SW="${MAIN_SWEEP:--1 1 2 7}"
          for v in $SW; do
            TAILN=0 run mt_$v 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --main-tile $v
