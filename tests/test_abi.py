@@ -96,6 +96,10 @@ def test_set_tuning_validates_and_resets(lib):
     L = lib.lib()
     t = lib.Tuning(9, 0, 0, 0)
     assert L.v2a_set_tuning(ctypes.byref(t)) == -1 and b"gemm_force_tile" in L.v2a_last_error()
+    t = lib.Tuning(4, 0, 0, 0)                                     # tile configuration 4 is not defined by the header
+    assert L.v2a_set_tuning(ctypes.byref(t)) == -1 and b"gemm_force_tile" in L.v2a_last_error()
+    t = lib.Tuning(3, 0, 1, 0, 5)                                  # valid tile, invalid dwconv rows: nothing may be applied
+    assert L.v2a_set_tuning(ctypes.byref(t)) == -1 and b"dwconv_rows_per_wave" in L.v2a_last_error()
     lib.set_tuning(force_tile=3, eight_phase=1)
     lib.set_tuning()
     assert L.v2a_set_tuning(None) == 0

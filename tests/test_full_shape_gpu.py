@@ -4,11 +4,12 @@ committed oracle vectors tests/golden/sample_full.npz (oracle/make_golden_full.p
   configs[0]  steps=4 plumbing case, fp32                         test_full_sample_steps4_fp32_vs_golden
   configs[1]  32-point grid, every grid point, fp32 < 1e-3        test_full_sample_steps32_fp32_every_grid_point
               same grid in the benchmarked bf16 mode (reported)   test_full_sample_steps32_bf16_report
-  configs[2]  8 clips per GPU, clip 3 == the B=1 vector           test_config2_eight_clips_per_gpu
+  configs[2]  8 clips per GPU, clip 3 == the B=1 vector           test_config2_eight_clips_per_gpu (steps=4, fp32 + bf16)
+              ... on the full 32-point grid, bf16x3 < 1e-3        test_config2_eight_clips_per_gpu_32_steps
   configs[3]  V2P roll, steps=4 vs golden + 64-step run           test_config3_v2p_roll_and_64_steps
-  configs[4]  3 cascaded passes == 3 independent calls            test_config4_cascade_equals_independent_calls
+  configs[4]  3 cascaded passes x 4 clips == independent calls    test_config4_cascade_equals_independent_calls
 
-The tolerance for fp32 mode is north_star's |delta mel| < 1e-3; bf16 numbers are printed and loosely bounded."""
+The tolerance for fp32 mode is north_star's |delta mel| < 1e-3; bf16 numbers are printed and bounded at ~1.5x what the mode measures today."""
 import os
 
 import numpy as np
@@ -134,7 +135,8 @@ def test_full_sample_steps32_bf16_report(full, mbf):
     err = (got[0] - f["g"]["y_steps32"]).abs()
     print("full-shape bf16 32-step sample: final max |delta mel| = %.4f mean %.5f; per grid point max: %s"
           % (float(err.max()), float(err.mean()), " ".join("%.3f" % v for v in d.amax(dim=(1, 2))[::4])))
-    assert float(err.mean()) < 0.1 and bool(torch.isfinite(got).all())
+    # ~1.5x what this mode measures today (max 0.050 - 0.055, mean 0.0087): an accuracy regression fails, the mode still carries no 1e-3 claim
+    assert float(err.max()) < 0.085 and float(err.mean()) < 0.014 and bool(torch.isfinite(got).all())
 
 
 def test_config2_eight_clips_per_gpu(full, m32, mbf):
@@ -154,7 +156,30 @@ def test_config2_eight_clips_per_gpu(full, m32, mbf):
     gb = _sample(mbf, f, 4, **kw)
     eb = (gb[3] - f["g"]["y_steps4"]).abs()
     print(f"configs[2] bf16: clip 3 of 8 vs B=1 golden max {float(eb.max()):.4f} mean {float(eb.mean()):.5f}")
-    assert float(eb.mean()) < 0.05 and bool(torch.isfinite(gb).all())
+    assert float(eb.max()) < 0.1 and float(eb.mean()) < 0.016 and bool(torch.isfinite(gb).all())
+
+
+def test_config2_eight_clips_per_gpu_32_steps(full, mbf):
+    """configs[2] at its real size: 8 clips per GPU on the full 32-point grid (31 CFG evaluations).  In the parity-grade
+    bf16x3 mode clip 3 of the batch carries the B=1 golden inputs and must land on the committed 32-step vector within
+    north_star's 1e-3; the same batch in the benchmarked bf16 mode is reported and bounded at ~1.5x today's distance."""
+    f = full
+    B = 8
+    y0, text, roll, ctx, cm = O.synthetic_inputs(f["cfg"], B, 750, nc=16, seed=21)
+    y0[3], text[3], roll[3], ctx[3] = f["y0"][0], f["text"][0], f["roll"][0], f["ctx"][0]
+    kw = dict(y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll)
+    m = make_model(f["cfg"], f["P"], "bf16x3")
+    got = _sample(m, f, 32, **kw)
+    del m
+    err = float((got[3] - f["g"]["y_steps32"]).abs().max())
+    print(f"configs[2] bf16x3, 8 clips x 32-point grid: clip 3 vs B=1 golden max |delta mel| = {err:.3e}")
+    assert err < 1e-3 and bool(torch.isfinite(got).all())
+    gb = _sample(mbf, f, 32, **kw)
+    eb = (gb[3] - f["g"]["y_steps32"]).abs()
+    dx = (gb - got).abs()
+    print(f"configs[2] bf16, 8 clips x 32-point grid: clip 3 vs golden max {float(eb.max()):.4f} mean {float(eb.mean()):.5f}; "
+          f"all 8 clips vs bf16x3 max {float(dx.max()):.4f} mean {float(dx.mean()):.5f}")
+    assert float(eb.max()) < 0.085 and float(eb.mean()) < 0.014 and float(dx.mean()) < 0.014 and bool(torch.isfinite(gb).all())
 
 
 def test_config3_v2p_roll_and_64_steps(full, m32, mbf):
@@ -180,7 +205,7 @@ def test_config4_cascade_equals_independent_calls(full, mbf):
     one model gives bit-for-bit what three calls on freshly planned models give -- no state leaks from pass to pass (the
     device step counter, modulation tables, cross-attention K/V and the captured graph are re-armed by every call)."""
     f = full
-    B = 2
+    B = 4                 # configs[4]: batch 32 on 8 GPUs = 4 clips per GPU
     ins = [O.synthetic_inputs(f["cfg"], B, 750, nc=16, seed=40 + i) for i in range(3)]
     def run(m, i):
         y0, text, roll, ctx, cm = ins[i]

@@ -339,6 +339,31 @@ def test_gemm_rejects_bad_args(L):
         L.gemm([(a, 40, 40)], w, out, M=4, N=16, compute=L.F32)
 
 
+def test_dwconv_rejects_bad_args(L):
+    """The depthwise-conv launch path answers V2A_ERR_ARG for what its kernels are not built for -- before anything reaches the
+    runtime (a process abort past the argument checks is what round 2's discarded one-channel-per-lane variant produced)."""
+    B, N, d = 2, 44, 96                                        # d % 32 == 0 but not a whole 256-channel block
+    x, out = torch.randn(B, N, d, device=DEV), torch.empty(B, N, d, device=DEV)
+    w, bias = torch.randn(31, d, device=DEV), torch.zeros(d, device=DEV)
+    hn, gam = torch.zeros(B * N, d, dtype=torch.bfloat16, device=DEV), torch.ones(d, device=DEV)
+    ssq = torch.zeros(B * N, d // 32, device=DEV)
+    L.dwconv(x, out, w, bias, B=B, N=N, d=d, ksize=31, norm=dict(out_bf16=hn, gamma=gam, ssq=ssq))        # supported
+    with pytest.raises(L.V2AError, match="kernel_size"):
+        L.dwconv(x, out, w[:7], bias, B=B, N=N, d=d, ksize=7)
+    with pytest.raises(L.V2AError, match="alias"):
+        L.dwconv(x, x, w, bias, B=B, N=N, d=d, ksize=31)
+    with pytest.raises(L.V2AError, match="folded norm"):                                                 # sums of squares narrower than d / 32
+        L.dwconv(x, out, w, bias, B=B, N=N, d=d, ksize=31, norm=dict(out_bf16=hn, gamma=gam, ssq=torch.zeros(B * N, 2, device=DEV)))
+    with pytest.raises(L.V2AError, match="folded norm"):                                                 # shadow rows narrower than d
+        L.dwconv(x, out, w, bias, B=B, N=N, d=d, ksize=31, norm=dict(out_bf16=hn, gamma=gam, ssq=ssq, ld_out_bf16=64))
+    x2 = torch.randn(B, N, 72, device=DEV)                                                                # d % 32 != 0
+    with pytest.raises(L.V2AError, match="folded norm"):
+        L.dwconv(x2, torch.empty_like(x2), w[:, :72].contiguous(), bias[:72], B=B, N=N, d=72, ksize=31,
+                 norm=dict(out_bf16=hn, gamma=gam, ssq=ssq))
+    with pytest.raises(L.V2AError, match="B=0"):
+        L.dwconv(x, out, w, bias, B=0, N=N, d=d, ksize=31)
+
+
 # ----------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, gate, kv_len, q_len, clamp=50.0):
     """q (B,H,Nq,64) etc. fp32 CPU."""
@@ -391,6 +416,35 @@ def test_attention(L, dt, B, H, Nq, Nk, kv_len, q_len, clamp):
     got = out.float().cpu().reshape(B, Nq, H, 64).permute(0, 2, 1, 3)
     tol = (2e-5 if code is None else 2e-4) if dt == torch.float32 else 2e-2
     torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, "split"])
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_attention_saturated_logits(L, dt, sign):
+    """Every logit at +-clamp (q . k * scale = +-2300 >> 50) over the largest key count of the path (782) with |v| = 8: the
+    bounded-weight kernels keep no running maximum, so their fp32 sums hold Nk * |v| * 2^(+-72) -- finite by the margin the
+    selection rule states (clamp * log2 e + log2 Nk <= 90).  All weights are equal, so the result is the mean of v."""
+    code = None
+    if dt == "split":
+        dt, code = torch.float32, L.BF16_SPLIT
+    B, H, N = 1, 2, 782
+    q = torch.full((B, N, H * 64 + 16), 12.0)
+    q[..., H * 64:] = 20.0                                  # gate: sigmoid(20) == 1 in fp32
+    kv = torch.full((B, N, 2 * H * 64), sign * 24.0)        # 64 * 12 * 24 * 0.125 = 2304
+    g = _g(3)
+    v = (torch.rand(B, N, H * 64, generator=g) * 2 - 1) * 8.0
+    kv[..., H * 64:] = v
+    qd, kvd = q.to(DEV, dt).contiguous(), kv.to(DEV, dt).contiguous()
+    out = torch.full((B, N, H * 64), float("nan"), dtype=dt, device=DEV)
+    es, inner = qd.element_size(), H * 64
+    L.attention(qd.data_ptr(), kvd.data_ptr(), kvd.data_ptr() + inner * es, qd.data_ptr() + inner * es, out.data_ptr(),
+                strides=(inner + 16, 2 * inner, 2 * inner, inner + 16, inner, N * (inner + 16), N * 2 * inner, N * 2 * inner,
+                         N * (inner + 16), N * inner),
+                B=B, H=H, Nq=N, Nk=N, scale=0.125, softclamp=50.0, dtype=L.dt_code(dt) if code is None else code)
+    got = out.float().cpu()
+    ref = kvd[..., inner:].float().cpu().mean(1, keepdim=True).expand(B, N, inner)
+    assert bool(torch.isfinite(got).all())
+    torch.testing.assert_close(got, ref, atol=2e-2 if dt == torch.bfloat16 else 1e-4, rtol=0)
 
 
 def test_attention_golden_self_and_cross(L, small, golden):

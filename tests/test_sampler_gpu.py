@@ -97,7 +97,7 @@ def test_sample_vs_golden_split_bf16(small, golden, case):
     assert err < TOL
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", TOL), ("bf16x3", TOL), ("bf16", 0.3)])
+@pytest.mark.parametrize("mode,tol", [("fp32", TOL), ("bf16x3", TOL), ("bf16", 0.05)])      # bf16 measures 0.032
 def test_audio_prompt_branch_vs_golden(small, mode, tol):
     """lens != duration: audio-prompted infilling (x3:2015-2035, 2196-2231, 2260-2261) against tests/golden/sample_small_prompt.npz:
     cond shorter than the longest duration (padding), different prompt lengths, a dropped prompt, and the per-forward API."""
@@ -190,7 +190,7 @@ def test_bf16_mode_error_is_bounded(small, golden):
                  remove_parallel_component=False, return_raw_output=True)
     err = np.abs(y.numpy() - g["y_full"])
     print(f"bf16 4-step sample: max |delta| = {err.max():.4f}, mean = {err.mean():.5f}")
-    assert err.max() < 0.25 and err.mean() < 0.02
+    assert err.max() < 0.06 and err.mean() < 0.013       # ~1.5x the measured 0.038 / 0.0085
 
 
 def test_missing_weights_and_unsupported_paths_raise(small):
@@ -326,3 +326,75 @@ def test_bf16_fused_cross_condition_and_skip_match_two_gemms(small, golden, case
     e = [float((o - torch.from_numpy(g[key])).abs().mean()) for o in outs]
     print(f"bf16 fused vs two-GEMM skip [{case}]: max {float(d.max()):.4f} mean {float(d.mean()):.5f}; mean |delta| vs fp32 golden {e[0]:.5f} / {e[1]:.5f}")
     assert float(d.mean()) < 0.02 and float(d.max()) < 0.3 and e[0] < 1.5 * e[1] + 0.01
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_plan_cache_and_buckets(small, mode):
+    """Real traffic (predict.py:210-237: captions and durations vary per clip).  (a) Alternating between two (frames, context)
+    shapes captures each graph once: returning to a shape is a plan + graph cache hit.  (b) With shape buckets
+    (E2TTS(bucket_frames=, bucket_ctx=)) both shapes share ONE plan and ONE graph, and the valid frames equal the unbucketed
+    results bit for bit in fp32 (the masks hide the padding; RoPE positions of the cross-attention keys stay those of the
+    unpadded call) -- in bf16 mode likewise, the padded rows only add masked work."""
+    i = small["inp"]
+    kw = dict(cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True, steps=4)
+    short = {k: v[:, :33] if k in ("y0", "text", "roll") else (v[:, :3] if k in ("ctx", "ctx_mask") else v) for k, v in i.items()}
+    exact = make_model(small["cfg"], small["P"], mode)
+    outs = {}
+    for rnd in range(3):
+        for name, x, n in (("long", i, 40), ("short", short, 33)):
+            y = exact.sample(torch.zeros(2, n, 16), y0=x["y0"], **_kw(x), **kw)
+            assert y.shape == (2, n, 16)
+            if rnd == 0:
+                outs[name] = y
+            else:
+                assert torch.equal(y, outs[name]), (name, rnd)
+    assert exact.graph_captures == 2, exact.graph_captures               # one capture per shape, none on the second and third visit
+    assert len(exact.engine().plans) == 2
+    buck = make_model(small["cfg"], small["P"], mode, bucket_frames=48, bucket_ctx=8)
+    for rnd in range(2):
+        for name, x, n in (("long", i, 40), ("short", short, 33)):
+            y = buck.sample(torch.zeros(2, n, 16), y0=x["y0"], **_kw(x), **kw)
+            assert y.shape == (2, n, 16)
+            d = float((y - outs[name]).abs().max())
+            print(f"bucketed (48 frames, 8 context tokens) vs exact plan [{mode}, {name}]: max |delta| = {d:.3e}")
+            assert torch.equal(y, outs[name]) if mode == "fp32" else d < 0.05, (name, d)
+    assert buck.graph_captures == 1 and len(buck.engine().plans) == 1, (buck.graph_captures, len(buck.engine().plans))
+    # a fifth distinct shape evicts the least recently used plan (max_plans = 4) without disturbing the others
+    for n in (20, 24, 28):
+        x = {k: v[:, :n] if k in ("y0", "text", "roll") else v for k, v in i.items()}
+        exact.sample(torch.zeros(2, n, 16), y0=x["y0"], **_kw(x), **kw)
+    assert len(exact.engine().plans) == 4 and exact.graph_captures == 5
+    y = exact.sample(torch.zeros(2, 33, 16), y0=short["y0"], **_kw(short), **kw)
+    assert torch.equal(y, outs["short"]) and exact.graph_captures == 5             # "short" was used after "long": still cached
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_graph_key_separates_prompted_and_unprompted_calls(mode):
+    """One model (if_cond_proj_in=True), one plan shape, graph on: a call without an audio prompt (lens == duration) followed by
+    one with a prompt and back.  embed() issues different launches with a prompt (position table with the bias, plus the
+    cond_proj_in GEMM), so the two must not share a captured graph: each graph-replayed result equals the eager one."""
+    import json, os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "sample_small_prompt.npz"), allow_pickle=False))
+    meta = json.loads(str(g["meta"]))
+    cfg = O.DiTConfig(**meta["cfg"])
+    P = O.init_params(cfg, meta["param_seed"])
+    tt = lambda k: torch.from_numpy(g[k])
+    base = dict(y0=tt("y0"), text_embed=tt("text"), context=tt("ctx"), context_mask=tt("ctx_mask"), frames_embed=tt("roll"),
+                steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False, return_raw_output=True)
+    n = tt("y0").shape[1]
+    # same plan shape and the same ragged durations (40, 33) in both kinds of call: only the prompt differs (clip 0 decides, x3:2224)
+    plain, prompted = dict(lens=tt("duration"), duration=tt("duration")), dict(lens=tt("lens"), duration=tt("duration"))
+    calls = [("plain", plain), ("prompt", prompted), ("plain", plain), ("prompt", prompted)]
+    res = {}
+    for use_graph in (False, True):
+        m = make_model(cfg, P, mode, use_graph=use_graph)
+        for k, (name, extra) in enumerate(calls):
+            cond = tt("cond") if name == "prompt" else torch.zeros(2, n, cfg.num_channels)
+            res[(use_graph, k)] = m.sample(cond, **base, **extra)
+        if use_graph:
+            assert m.graph_captures == 2 and len(m.engine().plans) == 1
+    for k, (name, _) in enumerate(calls):
+        assert torch.equal(res[(True, k)], res[(False, k)]), f"call {k} ({name}): graph replay differs from eager"
+    assert not torch.equal(res[(True, 0)], res[(True, 1)])
+    assert torch.equal(res[(True, 0)], res[(True, 2)]) and torch.equal(res[(True, 1)], res[(True, 3)])

@@ -14,7 +14,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("V2A_CFM_LIB") or os.path.join(_HERE, "libv2a_cfm.so")   # V2A_CFM_LIB: A/B tuning aid
+LIB_PATH = os.path.join(_HERE, "libv2a_cfm.so")      # in-tree, next to this file; nothing is read from the environment
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, BF16_SPLIT = 0, 1, 2

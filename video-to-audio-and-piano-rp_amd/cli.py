@@ -72,7 +72,12 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=64)                 # src/inference_v2a.py:183
     ap.add_argument("--cfg-strength", type=float, default=2.0)
     ap.add_argument("--frames", type=int, default=750, help="latent frames per clip (10 s)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "fp32"],
+                    help="bf16: fastest, |delta mel| ~ 5e-2 vs the fp32 reference arithmetic; bf16x3: split-bf16 products, < 1e-3 at ~0.4x the "
+                         "bf16 speed; fp32: exact-fp32 MFMA, < 1e-3 at ~0.18x")
+    ap.add_argument("--bucket-frames", type=int, default=64, help="pad plans to a multiple of this many latent frames (0 = exact shapes): "
+                    "durations vary per clip, and every new shape costs a plan and a hipGraph capture")
+    ap.add_argument("--bucket-ctx", type=int, default=16, help="pad the T5 context to a multiple of this many tokens (0 = exact)")
     ap.add_argument("--t5", default=None, help="local FLAN-T5 directory (reference: ./ckpts/flan-t5-large)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--model-config", default=None, help="JSON dict of transformer kwargs (default: predict.py:120-134)")
@@ -93,7 +98,7 @@ def main(argv=None):
     channels = tk.pop("num_channels", 128)
     model = E2TTS(transformer=dict(if_text_modules=True, if_cross_attn=True, if_audio_conv=True, if_text_conv=True, **tk),
                   num_channels=channels, sampling_rate=24000, if_cond_proj_in=False, tokenizer="phoneme_zh",
-                  compute_dtype=a.dtype, device=torch.device("cuda", local))
+                  compute_dtype=a.dtype, device=torch.device("cuda", local), bucket_frames=a.bucket_frames, bucket_ctx=a.bucket_ctx)
     ck = torch.load(a.ckpt, map_location="cpu")
     res = model.load_state_dict(ck.get("model_state_dict", ck), strict=False)      # predict.py:161-168
     if res.missing_keys:

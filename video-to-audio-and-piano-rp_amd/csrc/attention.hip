@@ -850,24 +850,35 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_f32_kernel(AttnParams p) {
 }
 
 template <int NG, int CLAMP>
-void launch_attn_f32(const AttnParams& p, dim3 grid, hipStream_t s) {
+int launch_attn_f32(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 68) * sizeof(float);
   auto kern = attn_mfma_f32_kernel<NG, CLAMP>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  (void)attr;
+  static std::atomic<uint64_t> lds_set{0};
+  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_attention")) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(256 * NG), smem, s, p);
+  return V2A_OK;
 }
 
 template <int NG, int CLAMP>
-void launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
+int launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 64) * sizeof(bf16_t);
   auto kern = attn_mfma_split_kernel<NG, CLAMP>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  (void)attr;
+  static std::atomic<uint64_t> lds_set{0};
+  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_attention")) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(256 * NG), smem, s, p);
+  return V2A_OK;
 }
 
 }  // namespace
+
+// 0 = no soft clamp, 1 = soft clamp with the running maximum, 2 = soft clamp with BOUNDED weights: logits lie in +-clamp, so
+// p = 2^(logit * log2 e) lies in 2^(+-clamp * log2 e) and no maximum has to be tracked -- as long as the fp32 sums l = sum p
+// and O = sum p v stay finite: Nk * max|v| * 2^(clamp * log2 e) < 2^128.  Mode 2 is taken while clamp * log2 e + log2 Nk <= 90
+// (the shipped clamp 50 with 782 keys: 72.1 + 9.6), which leaves |v| up to 2^38; beyond that the running-maximum kernel runs.
+static int attn_clamp_mode(float softclamp, int Nk) {
+  if (!(softclamp > 0.f)) return 0;
+  return softclamp * 1.4426950408889634f + log2f((float)(Nk > 1 ? Nk : 1)) <= 90.f ? 2 : 1;
+}
 
 extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   V2A_REQUIRE(a != nullptr, "v2a_attention: null args");
@@ -882,6 +893,7 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   p.kv_len = a->kv_len; p.q_len = a->q_len;
   p.scale = a->scale; p.clamp = a->softclamp;
   hipStream_t s = (hipStream_t)stream;
+  int rc = V2A_OK;
   dim3 grid((a->Nq + 63) / 64, a->H, a->B), block(64);
   if (a->dtype == V2A_BF16_SPLIT) {
     // fp32 tensors, split-bf16 MFMA arithmetic (bf16x3 mode); 16-byte aligned head slices and output rows, else the VALU kernel
@@ -889,34 +901,34 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
                          a->k_row_stride % 4 == 0 && a->v_row_stride % 4 == 0 && a->out_row_stride % 4 == 0 && a->q_batch_stride % 4 == 0 &&
                          a->k_batch_stride % 4 == 0 && a->v_batch_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
     const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
-    const int cl = a->softclamp > 0.f ? (a->softclamp * 1.4426950408889634f <= 100.f ? 2 : 1) : 0;
+    const int cl = attn_clamp_mode(a->softclamp, a->Nk);
     if (!aligned) {
       hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
     } else if (a->Nk > 128) {
-      if (cl == 2) launch_attn_split<2, 2>(p, g64, s);
-      else if (cl == 1) launch_attn_split<2, 1>(p, g64, s);
-      else launch_attn_split<2, 0>(p, g64, s);
+      if (cl == 2) rc = launch_attn_split<2, 2>(p, g64, s);
+      else if (cl == 1) rc = launch_attn_split<2, 1>(p, g64, s);
+      else rc = launch_attn_split<2, 0>(p, g64, s);
     } else {
-      if (cl == 2) launch_attn_split<1, 2>(p, g64, s);
-      else if (cl == 1) launch_attn_split<1, 1>(p, g64, s);
-      else launch_attn_split<1, 0>(p, g64, s);
+      if (cl == 2) rc = launch_attn_split<1, 2>(p, g64, s);
+      else if (cl == 1) rc = launch_attn_split<1, 1>(p, g64, s);
+      else rc = launch_attn_split<1, 0>(p, g64, s);
     }
   } else if (a->dtype == V2A_F32) {
     const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) == 0 && a->q_row_stride % 4 == 0 &&
                          a->k_row_stride % 4 == 0 && a->v_row_stride % 4 == 0 && a->out_row_stride % 4 == 0 && a->q_batch_stride % 4 == 0 &&
                          a->k_batch_stride % 4 == 0 && a->v_batch_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
     const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
-    const int cl = a->softclamp > 0.f ? (a->softclamp * 1.4426950408889634f <= 100.f ? 2 : 1) : 0;
+    const int cl = attn_clamp_mode(a->softclamp, a->Nk);
     if (!aligned) {
       hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
     } else if (a->Nk > 128) {
-      if (cl == 2) launch_attn_f32<2, 2>(p, g64, s);
-      else if (cl == 1) launch_attn_f32<2, 1>(p, g64, s);
-      else launch_attn_f32<2, 0>(p, g64, s);
+      if (cl == 2) rc = launch_attn_f32<2, 2>(p, g64, s);
+      else if (cl == 1) rc = launch_attn_f32<2, 1>(p, g64, s);
+      else rc = launch_attn_f32<2, 0>(p, g64, s);
     } else {
-      if (cl == 2) launch_attn_f32<1, 2>(p, g64, s);
-      else if (cl == 1) launch_attn_f32<1, 1>(p, g64, s);
-      else launch_attn_f32<1, 0>(p, g64, s);
+      if (cl == 2) rc = launch_attn_f32<1, 2>(p, g64, s);
+      else if (cl == 1) rc = launch_attn_f32<1, 1>(p, g64, s);
+      else rc = launch_attn_f32<1, 0>(p, g64, s);
     }
   } else {
     // MFMA path needs 16-byte aligned head slices for its vector loads and 8-byte aligned output rows
@@ -926,7 +938,7 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
                          a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
     const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
     // soft clamp with bounded weights (no running maximum) while 2^(clamp * log2 e) stays far inside fp32: clamp <= 69
-    const int cl = a->softclamp > 0.f ? (a->softclamp * 1.4426950408889634f <= 100.f ? 2 : 1) : 0;
+    const int cl = attn_clamp_mode(a->softclamp, a->Nk);
     // two wave groups split the key tiles of a workgroup's 64 queries (merged at the end) while the launch is short of
     // workgroups; from ~6 workgroups per CU on, one group per workgroup: no merge, 4-wave barriers
     const bool split_kv = a->Nk > 128 && (int64_t)g64.x * g64.y * g64.z < v2a_detail::g_attn_one_group_from;
@@ -942,5 +954,6 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
     else
       hipLaunchKernelGGL((attn_rowlane_kernel<bf16_t>), grid, block, 0, s, p);
   }
+  if (rc != V2A_OK) return rc;
   return v2a_check_launch("v2a_attention");
 }

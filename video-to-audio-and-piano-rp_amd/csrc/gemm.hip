@@ -129,9 +129,10 @@ int launch(const GemmParams& p, hipStream_t s) {
   constexpr size_t smem = 2 * (size_t)(BM + BN) * LR * sizeof(T);
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   auto kern = gemm_kernel<T, A_F32, EPI, OutT, BM, BN>;
-  // > 64 KB dynamic LDS is opt-in; a function-local static is initialised exactly once, thread-safely (C++11)
-  static const hipError_t attr = smem > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) : hipSuccess;
-  (void)attr;
+  if constexpr (smem > 48 * 1024) {
+    static std::atomic<uint64_t> lds_set{0};
+    if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm")) return rc;
+  }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), smem, s, p);
   return v2a_check_launch("v2a_gemm");
 }
@@ -374,8 +375,8 @@ int launch_dma(const GemmParams& p, hipStream_t s) {
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
   auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST>;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  (void)attr;
+  static std::atomic<uint64_t> lds_set{0};
+  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm(dma)")) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WGM * WGN), smem, s, p);
   return v2a_check_launch("v2a_gemm(dma)");
 }
@@ -418,12 +419,14 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
     v2a_detail::g_attn_one_group_from = 1536;
     return V2A_OK;
   }
+  // every field is checked before any is assigned: a rejected call leaves the previous tuning whole
   V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6, "v2a_set_tuning: dwconv_rows_per_wave %d",
               t->dwconv_rows_per_wave);
+  V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 8 && t->gemm_force_tile != 4, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
+  V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
+  V2A_REQUIRE(t->gemm_8phase_min_tiles >= 0 && t->attn_one_group_from >= 0, "v2a_set_tuning: negative threshold");
   v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave ? t->dwconv_rows_per_wave : 4;
   v2a_detail::g_attn_one_group_from = t->attn_one_group_from > 0 ? t->attn_one_group_from : 1536;
-  V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 8, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
-  V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
   v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,
                                t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,
                                t->gemm_xcd_order_1x8 ? 0 : 1};
@@ -591,9 +594,11 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   //     N <= 512 at 8 clips (653 vs 450 TF/s at 12512x512x2048);
   //   * 128x128 from ~2 clips, 64x64 below (one clip: only small tiles give every CU work).
   const bool can8 = tune.use_8phase && dense;
-  if (tune.force_tile == 6) return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
+  // a forced 8-phase kernel applies to dense launches only: it knows nothing of the implicit-GEMM offset tables (Video2Roll
+  // convolutions), which keep their by-shape choice
+  if (tune.force_tile == 6 && dense) return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
   int cfg;
-  if (tune.force_tile >= 0) cfg = tune.force_tile;
+  if (tune.force_tile >= 0 && tune.force_tile != 6) cfg = tune.force_tile;
   else if (a->N <= 64) cfg = ntiles(128, 64) >= 512 ? 2 : 3;          // conv layers with few output channels
   else if (a->N <= 128) cfg = ntiles(128, 128) >= 512 ? 1 : (ntiles(128, 64) >= 512 ? 2 : 3);
   else if (a->N >= 2048) {

@@ -230,13 +230,13 @@ int launch_8ph(const GemmParams& p, hipStream_t s) {
   const bool stagger = v2a_detail::g_gemm_tuning.use_8phase != 2;
   if (stagger) {
     auto kern = gemm_bf16_8ph_kernel<EPI, OutT, true>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)attr;
+    static std::atomic<uint64_t> lds_set{0};
+    if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm(8-phase)")) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, s, p);
   } else {
     auto kern = gemm_bf16_8ph_kernel<EPI, OutT, false>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)attr;
+    static std::atomic<uint64_t> lds_set{0};
+    if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm(8-phase)")) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), smem, s, p);
   }
   return v2a_check_launch("v2a_gemm(8-phase)");

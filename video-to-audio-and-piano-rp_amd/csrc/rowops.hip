@@ -545,12 +545,42 @@ static int dwconv_launch(const float* x, float* out, const float* wt, const floa
   const int cap = max(1, (TN == 4 ? 3 : 2) * 256 / 8 / cb);
   const int rounds = (ipx + cap - 1) / cap;
   const int walkers = (ipx + rounds - 1) / rounds;
+  V2A_REQUIRE(walkers >= 1 && (int64_t)walkers * 8 <= 65535 && (int64_t)walkers * rounds * 8 >= items,
+              "v2a_dwconv: grid does not cover the work (items=%d walkers=%d rounds=%d)", items, walkers, rounds);
   dim3 grid(cb, walkers * 8), block(256);
   const v2a_dwconv_norm none{};
   hipStream_t s = (hipStream_t)stream;
-  if (norm) hipLaunchKernelGGL((dwconv_kernel<31, 4, true>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, *norm);
-  else if (TN == 6) hipLaunchKernelGGL((dwconv_kernel<31, 6, false>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, none);
-  else hipLaunchKernelGGL((dwconv_kernel<31, 4, false>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, none);
+  // The instantiation that is about to run must be launchable as compiled: 256 threads inside its register budget
+  // (__launch_bounds__(256, 3) = 168 VGPRs; a variant that needs more is built with a smaller maxThreadsPerBlock) and its static
+  // tap stage inside the 64 KB a kernel gets without opting in.  Asked once per (instantiation, device); a variant that does not
+  // fit is refused here with V2A_ERR_ARG instead of reaching the runtime.
+  auto launchable = [&](const void* kern, std::atomic<uint64_t>& done, const char* what) -> int {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return V2A_OK;
+    hipFuncAttributes fa{};
+    const hipError_t e = hipFuncGetAttributes(&fa, kern);
+    if (e != hipSuccess) return v2a_fail(V2A_ERR_LAUNCH, "v2a_dwconv(%s): hipFuncGetAttributes: %s", what, hipGetErrorString(e));
+    if (fa.maxThreadsPerBlock < 256 || fa.sharedSizeBytes > 64 * 1024)
+      return v2a_fail(V2A_ERR_ARG, "v2a_dwconv(%s): kernel variant not launchable with 256 threads (max threads %d, %d VGPRs, %zu bytes of LDS)", what,
+                      fa.maxThreadsPerBlock, fa.numRegs, (size_t)fa.sharedSizeBytes);
+    done.fetch_or(bit, std::memory_order_release);
+    return V2A_OK;
+  };
+  if (norm) {
+    static std::atomic<uint64_t> ok{0};
+    if (int rc = launchable(reinterpret_cast<const void*>(dwconv_kernel<31, 4, true>), ok, "rows 4, folded norm")) return rc;
+    hipLaunchKernelGGL((dwconv_kernel<31, 4, true>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, *norm);
+  } else if (TN == 6) {
+    static std::atomic<uint64_t> ok{0};
+    if (int rc = launchable(reinterpret_cast<const void*>(dwconv_kernel<31, 6, false>), ok, "rows 6")) return rc;
+    hipLaunchKernelGGL((dwconv_kernel<31, 6, false>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, none);
+  } else {
+    static std::atomic<uint64_t> ok{0};
+    if (int rc = launchable(reinterpret_cast<const void*>(dwconv_kernel<31, 4, false>), ok, "rows 4")) return rc;
+    hipLaunchKernelGGL((dwconv_kernel<31, 4, false>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, none);
+  }
   return v2a_check_launch("v2a_dwconv_silu_residual");
 }
 

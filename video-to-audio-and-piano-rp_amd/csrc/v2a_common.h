@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/v2a_cfm.h"
 
@@ -33,6 +34,20 @@ static inline int v2a_fail(int code, const char* fmt, ...) {
 static inline int v2a_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return v2a_fail(V2A_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return V2A_OK;
+}
+
+// More than 64 KB of dynamic LDS is opt-in per kernel AND per device: `done` (one static per call site = per kernel
+// instantiation) holds one bit per device ordinal, so a process that launches on a second GPU sets the attribute there too, and a
+// failing attribute call is reported as itself instead of as an opaque launch error later.
+static inline int v2a_enable_lds(const void* kern, size_t bytes, std::atomic<uint64_t>& done, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return V2A_OK;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return v2a_fail(V2A_ERR_LAUNCH, "%s: hipFuncSetAttribute(%zu bytes of LDS) on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+  done.fetch_or(bit, std::memory_order_release);
   return V2A_OK;
 }
 

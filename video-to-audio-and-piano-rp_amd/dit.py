@@ -24,6 +24,7 @@ dtype (bf16, or fp32 in parity mode) and live in per-stream scratch buffers size
 from __future__ import annotations
 
 import math
+from collections import OrderedDict
 from dataclasses import dataclass, asdict
 
 import torch
@@ -279,21 +280,29 @@ class DiTEngine:
         self.softclamp = float(softclamp)
         L.lib()  # fail loudly now if the HIP library is absent
         self.W = PackedWeights(cfg, state_dict, self.dev, self.cd, self.split)
+        # plans (buffers + the hipGraphs captured on them, see E2TTS._run_steps) by shape, least recently used first: captions and
+        # durations vary per clip (predict.py:210-237), and a plan switch otherwise costs ~0.5 GB of allocations, an eager warm-up
+        # evaluation and a re-capture.  A B = 1 plan is < 0.5 GB, 8 clips ~4 GB: nothing next to 288 GB of HBM.
+        self.plans: OrderedDict = OrderedDict()
+        self.max_plans = 4
         self.plan = None
 
     # ------------------------------------------------------------------------------ planning
     def setup(self, B: int, T: int, nc: int, S: int, cfg_mode: bool = True):
         """B clips, T latent frames, nc context tokens, S time points (Euler evaluations)."""
         key = (B, T, nc, S, cfg_mode)
-        if self.plan is not None and self.plan["key"] == key:
-            return self.plan
+        p = self.plans.get(key)
+        if p is not None:
+            self.plans.move_to_end(key)
+            self.plan = p
+            return p
         c, dev, cd = self.cfg, self.dev, self.cd
         R = c.num_registers
         N = T + R
         Bt = 2 * B if cfg_mode else B
         rows = Bt * N
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
-        p = dict(key=key, B=B, Bt=Bt, T=T, N=N, nc=nc, S=S, rows=rows, cfg_mode=cfg_mode)
+        p = dict(key=key, B=B, Bt=Bt, T=T, N=N, nc=nc, S=S, rows=rows, cfg_mode=cfg_mode, graphs={})
         D, Dt, Df = c.dim, c.dim_text, c.dim_frames
         p["xA"], p["xB"], p["xS"] = e(Bt, N, D), e(Bt, N, D), e(Bt, N, D)
         p["skips"] = [e(Bt, N, D) for _ in range(c.depth // 2)]
@@ -346,8 +355,10 @@ class DiTEngine:
         p["ragged"] = False
         # rotary table (A6): cos/sin of pos * 10000^(-2i/64), computed like the oracle (CPU fp32)
         inv = 1.0 / (10000 ** (torch.arange(0, c.dim_head, 2).float() / c.dim_head))
-        ang = torch.arange(N).float()[:, None] * inv[None, :]
-        p["rope"] = torch.stack((ang.cos(), ang.sin()), -1).contiguous().to(dev)            # (N, 32, 2)
+        # N + nc rows: with a bucketed plan (E2TTS(bucket_ctx=...)) the cross-attention keys sit at the positions of the
+        # UNPADDED lengths (prepare(rope_len=, rope_ctx_len=)), and the masked padding keys behind them still index the table
+        ang = torch.arange(N + nc).float()[:, None] * inv[None, :]
+        p["rope"] = torch.stack((ang.cos(), ang.sin()), -1).contiguous().to(dev)            # (N + nc, 32, 2)
         p["per_sample_t"] = False
         p["has_cond"] = False
         if c.cond_proj_in:          # operand of the audio-prompt GEMM: (B, N, Kp) rows incl. zero register rows; pos_emb + bias table
@@ -357,7 +368,18 @@ class DiTEngine:
         if self.dev.type == "cuda" and self.multi_stream:
             p["st"], p["sf"], _ = process_streams(self.dev)
         self.plan = p
+        self.plans[key] = p
+        while len(self.plans) > max(1, self.max_plans):
+            self.plans.popitem(last=False)          # drops the plan's buffers and graphs
         return p
+
+    def launch_signature(self):
+        """Everything besides the plan's shape that changes the LAUNCH SEQUENCE of euler_step (part of the key of a captured graph):
+        the tuning knobs on this object and the per-call state prepare() leaves in the plan."""
+        p = self.plan
+        return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
+                tuple(sorted(self.big_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.cross_on_main,
+                self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
     def _sh(self, buf):
@@ -534,7 +556,7 @@ class DiTEngine:
 
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
-                drop_text=None, drop_ctx=None, dt=None, step_cond=None):
+                drop_text=None, drop_ctx=None, dt=None, step_cond=None, rope_len=None, rope_ctx_len=None):
         """Everything that is constant over the Euler loop.
         text (B,T,Dt) f32 CLIP features, frames_roll (B,T,51) f32, context (B,nc,ctx) f32,
         context_mask (B,nc) bool (prefix form), t_points (S,) f32 (host or device),
@@ -542,7 +564,10 @@ class DiTEngine:
         bool lists of length Bt / B (cfg_mode fills the null half itself).
         step_cond (B,T,C) f32 or None: the masked audio prompt of the infilling branch (x3:2228), already zeroed where dropped;
         it enters every evaluation as x += cond_proj_in(step_cond) on the conditional half and + bias on the null half
-        (x3:2015-2035: a dropped cond is zero, the bias stays)."""
+        (x3:2015-2035: a dropped cond is zero, the bias stays).
+        rope_len / rope_ctx_len: sequence length (registers + frames) and context length the REFERENCE call would have had when
+        the plan is padded to a bucket (defaults: the plan's N and nc): the cross-attention keys are rotated with the last
+        rope_ctx_len positions of a rope_len-long table (A7), which padding must not move."""
         p, c, W, dev = self.plan, self.cfg, self.W, self.dev
         B, Bt, T, N, nc, S = p["B"], p["Bt"], p["T"], p["N"], p["nc"], p["S"]
         R, D, Dt, Df = c.num_registers, c.dim, c.dim_text, c.dim_frames
@@ -611,8 +636,10 @@ class DiTEngine:
         nkv = 2 * c.depth * inner
         self._mm([(p["ctx"], c.ctx_dim, c.ctx_dim)], W.ctx_kv_w, p["ctx_kv"], M=B * nc, N=nkv, ldo=nkv)
         if self.rope_cross:                                   # A7: keys take the LAST nc table rows
+            off = (N if rope_len is None else int(rope_len)) - (nc if rope_ctx_len is None else int(rope_ctx_len))
+            assert 0 <= off and off + nc <= p["rope"].shape[0], (off, nc, N)
             L.rope(p["ctx_kv"], rows=B * nc, row_stride=nkv, nheads=c.depth * c.heads, rows_per_batch=nc,
-                   pos_offset=N - nc, table=p["rope"], layout=self.rope_layout)
+                   pos_offset=off, table=p["rope"], layout=self.rope_layout)
         # -- hoisted layer-0 text / frames blocks
         ly = W.layers[0]
         self._side_block(ly, "t", p["t0"], p["tL0"], Bt, Dt)

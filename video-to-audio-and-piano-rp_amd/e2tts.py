@@ -156,6 +156,8 @@ class E2TTS:
         rope_layout: str = "interleaved",
         rope_cross: bool = True,
         use_graph: bool = True,              # capture the Euler step in a hipGraph
+        bucket_frames: int = 0,              # > 0: plans are padded to a multiple of this many latent frames (ragged masks hide the padding)
+        bucket_ctx: int = 0,                 # > 0: ... and to a multiple of this many context tokens (context_mask hides the padding)
         video_encoder_fn: Callable | None = None,   # (video_paths, n) -> (b, n, dim_text)
         text_encoder_fn: Callable | None = None,    # (prompts) -> ((b, nc, ctx) float, (b, nc) bool)
         frames_encoder_fn: Callable | None = None,  # (frames, n) -> (b, n, NOTES)
@@ -192,11 +194,16 @@ class E2TTS:
         self._compute = compute_dtype
         self._rope = (rope_layout, rope_cross)
         self._use_graph = use_graph
+        # Shape buckets: captions and durations vary per clip (predict.py:210-237), and every new (frames, context) shape costs a
+        # plan, an eager warm-up evaluation and a graph capture.  With buckets, sample() pads the latent frames and the context to
+        # the bucket and lets the length masks (lens_to_mask x3:296-305, context_mask) hide the padding; results of the valid
+        # frames do not change (tests/test_sampler_gpu.py::test_plan_cache_and_buckets).  0 = exact shapes.
+        self.bucket_frames, self.bucket_ctx = int(bucket_frames), int(bucket_ctx)
+        self.graph_captures = 0              # hipGraph captures so far (a plan / graph cache hit leaves it unchanged)
         self.video_encoder_fn, self.text_encoder_fn, self.frames_encoder_fn = video_encoder_fn, text_encoder_fn, frames_encoder_fn
         self._shapes = expected_state_dict_shapes(self.cfg)
         self._sd: dict[str, torch.Tensor] = {}
         self._engine: DiTEngine | None = None
-        self._graphs: dict = {}
         self._v2r_sd, self._v2r = None, None      # optional Video2Roll frame encoder (video2roll_net.*, x3:1523)
         L.lib()  # no library -> no sampler
 
@@ -252,8 +259,7 @@ class E2TTS:
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict(strict=True): missing {missing[:5]}..., unexpected {unexpected[:5]}...")
         self._sd.update(new)
-        self._engine = None
-        self._graphs = {}
+        self._engine = None          # plans and their graphs go with the engine
         return _IncompatibleKeys(missing, unexpected)
 
     def engine(self) -> DiTEngine:
@@ -379,7 +385,9 @@ class E2TTS:
         cfgm = self.cfg
         # -- frames / piano roll (x3:2164-2176)
         if frames_embed is None:
-            if frames is None:
+            if frames is None or isinstance(frames, (int, float)):
+                # no frames (V2A): all-zero roll (x3:2164-2165).  predict.py:270 also lets a float placeholder through, which the
+                # reference's encode_frames would fail on (`x.shape`, x3:1527); here it means "no frames" instead of reaching the encoder
                 frames_embed = torch.zeros(batch, cond_seq_len, cfgm.notes)
             elif self.frames_encoder_fn is not None:
                 frames_embed = self.frames_encoder_fn(frames, cond_seq_len)
@@ -443,20 +451,30 @@ class E2TTS:
         S = steps - 1
         if y0 is None:
             y0 = torch.randn(batch, n, cfgm.num_channels, device=self._device)
+        # -- shape buckets (constructor): pad frames / context, the masks hide the padding; RoPE positions of the cross-attention
+        #    keys stay those of the unpadded call (DiTEngine.prepare)
+        nc = context.shape[1]
+        n_plan = -(-n // self.bucket_frames) * self.bucket_frames if self.bucket_frames > 0 else n
+        nc_plan = -(-nc // self.bucket_ctx) * self.bucket_ctx if self.bucket_ctx > 0 else nc
+        pad_t = lambda x: x if x is None or x.shape[1] == n_plan else torch.nn.functional.pad(x, (0, 0, 0, n_plan - x.shape[1]))
+        if nc_plan != nc:
+            context = torch.nn.functional.pad(context, (0, 0, 0, nc_plan - nc))
+            context_mask = torch.nn.functional.pad(context_mask.to(torch.bool), (0, nc_plan - nc))
         eng = self.engine()
-        eng.setup(batch, n, context.shape[1], S, cfg_mode=True)
+        eng.setup(batch, n_plan, nc_plan, S, cfg_mode=True)
         p = eng.plan
         if "y" not in p:
-            p["y"] = torch.empty(batch, n, cfgm.num_channels, dtype=torch.float32, device=self._device)
+            p["y"] = torch.empty(batch, n_plan, cfgm.num_channels, dtype=torch.float32, device=self._device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
-        eng.prepare(text_embed, frames_embed, context, context_mask, t[:-1], lens=duration,
-                    drop_ctx=drop_ctx, dt=t[1:] - t[:-1], step_cond=step_cond)
+        eng.prepare(pad_t(text_embed), pad_t(frames_embed), context, context_mask, t[:-1], lens=duration,
+                    drop_ctx=drop_ctx, dt=t[1:] - t[:-1], step_cond=pad_t(step_cond),
+                    rope_len=cfgm.num_registers + n, rope_ctx_len=nc)
         ev[1].record()
-        self._run_steps(eng, y0, S, float(cfg_strength), bool(remove_parallel_component), trajectory_out)
+        self._run_steps(eng, pad_t(y0), S, float(cfg_strength), bool(remove_parallel_component), trajectory_out, n)
         ev[2].record()
         self._phase_events = ev          # device-side phase marks of this call (no host sync here): see phase_ms()
-        out = p["y"].to(out_device).clone()
+        out = p["y"][:, :n].to(out_device).clone()
         if step_cond is not None:
             out = torch.where(cond_mask.to(out_device), condp.to(out_device), out)        # x3:2260-2261: the prompt frames come back unchanged
         if return_raw_output:
@@ -485,7 +503,7 @@ class E2TTS:
         ev[2].synchronize()
         return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
 
-    def _run_steps(self, eng: DiTEngine, y0, S, cfg_strength, apg, traj=None):
+    def _run_steps(self, eng: DiTEngine, y0, S, cfg_strength, apg, traj=None, n_valid=None):
         """steps-1 Euler evaluations (A12 of SURVEY 8c).  cfg_strength < 1e-5 (x3:2101) still
         runs the batched pass; the null half then has weight 0."""
         p = eng.plan
@@ -493,15 +511,18 @@ class E2TTS:
         y.copy_(y0.to(self._device, torch.float32))
         p["step"].zero_()
         if traj is not None:
-            traj.append(y.clone())
+            traj.append(y[:, :n_valid].clone())
         if not self._use_graph:
             for _ in range(S):
                 eng.euler_step(y, cfg_strength, apg)
                 if traj is not None:
-                    traj.append(y.clone())
+                    traj.append(y[:, :n_valid].clone())
             return
-        key = (p["key"], cfg_strength, apg, p["ragged"])
-        g = self._graphs.get(key)
+        # graphs live in the plan they were captured on (DiTEngine keeps the last few plans, least recently used first); the key
+        # holds everything that changes the captured launch sequence: embed() and forward() issue different launches with an
+        # audio prompt (has_cond), ragged lengths, or any tuning knob of the engine
+        key = (cfg_strength, apg, eng.launch_signature())
+        g = p["graphs"].get(key)
         if g is None:
             # warm-up on the real buffers (first-launch attribute calls must not happen under capture)
             keep = y.clone()
@@ -514,11 +535,12 @@ class E2TTS:
             # (RCCL under torch.distributed) polling its events meanwhile cannot invalidate the capture
             with torch.cuda.graph(g, stream=process_streams(self._device)[2], capture_error_mode="thread_local"):
                 eng.euler_step(y, cfg_strength, apg)
-            self._graphs = {key: g}          # one plan is live at a time; drop graphs of older plans
+            p["graphs"][key] = g
+            self.graph_captures += 1
         for _ in range(S):
             g.replay()
             if traj is not None:
-                traj.append(y.clone())
+                traj.append(y[:, :n_valid].clone())
 
 
 def _mask_to_lens(mask: torch.Tensor) -> torch.Tensor:
