@@ -49,6 +49,7 @@ for s in "$@"; do
     enc) run enc 600 python -m pytest tests/test_encodec_gpu.py -q -m gpu -x --tb=short -s ;;
     full) TAILN=40 run full 900 python -m pytest tests/test_full_shape_gpu.py -q -m gpu --tb=short -s ;;
     alltests) run alltests 1100 python -m pytest tests -q -m gpu -x --tb=short ;;
+    alltests_s) TAILN=60 run alltests_s 1100 python -m pytest tests -q -m gpu --tb=short -s ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) TAILN=4 run bench 900 python bench.py --steps 5 --warmup 2 ;;
     ab8) for v in "0 0" "1 200" "1 80"; do set -- $v
@@ -107,6 +108,11 @@ for s in "$@"; do
            TAILN=0 run mt_$v 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched --main-tile $v
            echo "--- main_tile=$v: $(grep -o '"value": [0-9.]*' gpurun_out/mt_$v.log | head -1)"
          done ;;
+    dist2) # two ranks of the REAL sampler (graph on) + one all-gather on the one device, gloo; the launcher touches no GPU
+           for m in bf16 bf16x3; do
+             TAILN=6 run dist2_$m 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 scripts/dist_rehearsal.py $m 5
+           done
+           cat gpurun_out/dist2_bf16.log gpurun_out/dist2_bf16x3.log | grep -E "^rank|REHEARSAL" > gpurun_out/dist_rehearsal.txt ;;
     bench2) V2A_BENCH_BACKEND=gloo run bench2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 ;;
     batch) for b in 2 4 8; do
              TAILN=0 run batch_$b 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --clips-per-gpu $b

@@ -97,7 +97,7 @@ def test_sample_vs_golden_split_bf16(small, golden, case):
     assert err < TOL
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", TOL), ("bf16x3", TOL), ("bf16", 0.05)])      # bf16 measures 0.032
+@pytest.mark.parametrize("mode,tol", [("fp32", TOL), ("bf16x3", TOL), ("bf16", 0.065)])      # bf16 measures 0.032 - 0.043
 def test_audio_prompt_branch_vs_golden(small, mode, tol):
     """lens != duration: audio-prompted infilling (x3:2015-2035, 2196-2231, 2260-2261) against tests/golden/sample_small_prompt.npz:
     cond shorter than the longest duration (padding), different prompt lengths, a dropped prompt, and the per-forward API."""
@@ -300,7 +300,7 @@ def test_bf16_folded_norms_match_separate_norm_kernels(small, golden, case):
         outs.append(o.float().cpu())
     d = (outs[0] - outs[1]).abs()
     print(f"bf16 folded vs separate norms [{case}]: max {float(d.max()):.4f} mean {float(d.mean()):.5f} (|y| max {float(outs[1].abs().max()):.2f})")
-    assert float(d.mean()) < 0.02 and float(d.max()) < 0.3
+    assert float(d.mean()) < 0.013 and float(d.max()) < 0.06        # ~1.5x the measured 0.0087 / 0.038
 
 
 @pytest.mark.parametrize("case", ["full", "ragged"])
@@ -325,7 +325,7 @@ def test_bf16_fused_cross_condition_and_skip_match_two_gemms(small, golden, case
     d = (outs[0] - outs[1]).abs()
     e = [float((o - torch.from_numpy(g[key])).abs().mean()) for o in outs]
     print(f"bf16 fused vs two-GEMM skip [{case}]: max {float(d.max()):.4f} mean {float(d.mean()):.5f}; mean |delta| vs fp32 golden {e[0]:.5f} / {e[1]:.5f}")
-    assert float(d.mean()) < 0.02 and float(d.max()) < 0.3 and e[0] < 1.5 * e[1] + 0.01
+    assert float(d.mean()) < 0.013 and float(d.max()) < 0.065 and e[0] < 1.2 * e[1] + 0.002     # measured 0.0088 / 0.042; 0.0081 vs 0.0088
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
