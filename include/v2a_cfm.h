@@ -51,7 +51,7 @@ enum {
   V2A_ERR_LAUNCH = -2  /* hipGetLastError() after launch */
 };
 
-int v2a_abi_version(void);        /* 4 */
+int v2a_abi_version(void);        /* 5 */
 const char* v2a_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -134,6 +134,21 @@ typedef struct v2a_gemm_args {
   const float* row_ssq;
   int64_t ld_row_ssq;
   int32_t row_ssq_parts, row_norm_dim;
+  /* XCD-subset placement (bf16 x bf16 LDS-DMA ring kernels; ignored by the others).  xcd_mask: bit x set = the launch may use
+   * XCD x (0 or 0xFF = all eight, the default placement).  With a proper subset the grid is 8 * ceil(tiles / XCDs in the mask)
+   * workgroups; one that finds itself on an XCD of the mask (HW_REG_XCC_ID) claims the next tile of that XCD's contiguous chunk
+   * of the tile order through tile_counters, the others return at once -- so three concurrent streams can each keep their
+   * operands in the L2s of their own XCDs instead of spreading every small GEMM over all eight.  tile_counters: 16 int32 in
+   * device memory, zeroed once by the caller and private to ONE stream (launches that may overlap need their own): the last
+   * workgroup to claim re-arms them for the next launch.  Which workgroup computes which tile depends on the placement; the
+   * result does not. */
+  int32_t* tile_counters;
+  int32_t xcd_mask;
+  /* non-zero: the out_bf16 shadow is written in the V2A_BF16_SPLIT layout, row m = [hi_0 .. hi_{N-1} | lo_0 .. lo_{N-1}] of the
+   * (gamma-scaled, when norm_gamma is given) fp32 result, ld_out_bf16 >= 2 * N: the operand of a later split-bf16 GEMM without a
+   * v2a_split_bf16 pass.  Likewise out_dtype = V2A_BF16_SPLIT (GEGLU epilogue only): out row m = [hi | lo] planes of the N/2
+   * hidden values, ldo >= N, exact erf GELU. */
+  int32_t out_bf16_split;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);

@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
         ("norm_switch_row", C.c_int32), ("norm_switch_offset", C.c_int32),
         ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64),
         ("row_ssq", C.c_void_p), ("ld_row_ssq", C.c_int64), ("row_ssq_parts", C.c_int32), ("row_norm_dim", C.c_int32),
+        ("tile_counters", C.c_void_p), ("xcd_mask", C.c_int32), ("out_bf16_split", C.c_int32),
     ]
 
 
@@ -104,7 +105,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-ABI_VERSION = 4          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
+ABI_VERSION = 5          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
 
 
 def _declare(lib):
@@ -281,7 +282,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
          a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0,
          norm_gamma=None, norm_step_stride=0, norm_batch_stride=0, norm_switch_row=0, norm_switch_offset=0, norm_ssq=None,
-         row_ssq=None, row_norm_dim=0):
+         row_ssq=None, row_norm_dim=0, xcd_mask=0, tile_counters=None, out_bf16_split=False):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype.
     Folded RMSNorm (v2a_gemm_args): producer -- norm_gamma (+ strides / switch) scales the out_bf16 shadow, norm_ssq (rows, N/32)
     receives the sums of squares; consumer -- row_ssq (rows, parts) of its A rows and row_norm_dim = their width."""
@@ -324,6 +325,8 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.ld_row_ssq = row_ssq.stride(-2) if row_ssq is not None else 0
     g.row_ssq_parts = row_norm_dim // 32 if row_ssq is not None else 0
     g.row_norm_dim = row_norm_dim
+    g.tile_counters, g.xcd_mask = _p(tile_counters), xcd_mask
+    g.out_bf16_split = 1 if out_bf16_split else 0
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")

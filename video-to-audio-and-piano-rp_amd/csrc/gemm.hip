@@ -206,7 +206,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   int tm, tn;
-  tile_of_block(blockIdx.x, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
+  if (p.tile_ctr) {
+    // XCD-subset placement: one lane asks which XCD the workgroup landed on; on an XCD of the mask it claims the next tile of that
+    // XCD's contiguous chunk of the rectangle order (chunk j of xcd_cnt for the j-th XCD of the mask), elsewhere -- or once the
+    // chunk is used up -- the workgroup leaves.  Which workgroup computes which tile depends on the placement, the result does not.
+    int* slot = reinterpret_cast<int*>(smem_raw + NST * STAGE_BYTES + BM * 4);
+    if (tid == 0) {
+      const int xcc = xcc_id();
+      int L = -1;
+      if ((p.xcd_mask >> xcc) & 1) {
+        const int j = __builtin_popcount(p.xcd_mask & ((1 << xcc) - 1));
+        const int nwg = tiles_m * tiles_n;
+        const int lo = (int)((int64_t)nwg * j / p.xcd_cnt), hi = (int)((int64_t)nwg * (j + 1) / p.xcd_cnt);
+        const int t = __hip_atomic_fetch_add(p.tile_ctr + 2 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lo + t < hi) L = lo + t;
+      }
+      // arrival count: the last workgroup to have claimed re-arms the counters for the next launch on them (the claim above has
+      // returned before the arrival is issued: the two go to different L2 channels)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int a = __hip_atomic_fetch_add(p.tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) p.tile_ctr[2 + x] = 0;
+        p.tile_ctr[0] = 0;
+      }
+      *slot = L;
+    }
+    __syncthreads();
+    const int L = __builtin_amdgcn_readfirstlane(*slot);
+    if (L < 0) return;
+    tile_of_index(L, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
+  } else {
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[TM][TN];
@@ -370,8 +402,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 
 template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST>
 int launch_dma(const GemmParams& p, hipStream_t s) {
-  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 + BM * 4;    // the ring + one row scale per tile row (folded RMSNorm)
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 + BM * 4 + 16;    // the ring + one row scale per tile row (folded RMSNorm) + the claimed tile
+  int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  // XCD-subset placement: workgroups are dealt round-robin over the 8 XCDs, so 8 * ceil(tiles / XCDs in the mask) of them put
+  // enough on every XCD of the mask to claim its chunk; the rest leave at once
+  if (p.tile_ctr) tiles = 8 * ((tiles + p.xcd_cnt - 1) / p.xcd_cnt);
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
   auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST>;
@@ -507,6 +542,24 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     }
     p.xcd_gm = best_gm;
     p.xcd_gn = 8 / best_gm;
+  }
+  p.tile_ctr = nullptr;
+  if (a->xcd_mask && (a->xcd_mask & 0xFF) != 0xFF) {
+    V2A_REQUIRE(a->tile_counters != nullptr && ((uintptr_t)a->tile_counters & 3) == 0, "v2a_gemm: xcd_mask needs tile_counters (16 zeroed int32)");
+    p.tile_ctr = a->tile_counters;
+    p.xcd_mask = a->xcd_mask & 0xFF;
+    p.xcd_cnt = __builtin_popcount(p.xcd_mask);
+    // rectangles over the XCDs of the mask
+    const double ab = (double)a->M * K * 2, wb = (double)a->N * K * 2;
+    int best_gm = 1;
+    double best = ab * p.xcd_cnt + wb;
+    for (int gm = 2; gm <= p.xcd_cnt; ++gm) {
+      if (p.xcd_cnt % gm) continue;
+      const double c = ab * (p.xcd_cnt / gm) + wb * gm;
+      if (c < best * 0.95) { best = c; best_gm = gm; }
+    }
+    p.xcd_gm = best_gm;
+    p.xcd_gn = p.xcd_cnt / best_gm;
   }
   p.a_rowoff = a->a_row_offset;
   p.a_koff = a->a_ktile_offset;

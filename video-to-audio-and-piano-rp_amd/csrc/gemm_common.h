@@ -48,7 +48,11 @@ struct GemmParams {
   int64_t rssq_ld;
   int32_t rssq_parts;
   float rnorm;
-  int32_t xcd_gm, xcd_gn;   // the 8 XCDs as a gm x gn grid over the tile space (gm * gn == 8): see tile_of_block
+  int32_t xcd_gm, xcd_gn;   // the XCDs of the launch as a gm x gn grid over the tile space (gm * gn == 8, or == the XCDs of xcd_mask): see tile_of_block
+  // XCD-subset placement (v2a_gemm_args.xcd_mask / tile_counters): workgroups that find themselves on an XCD of the mask claim the
+  // tiles of that XCD's chunk through a device counter, the others leave at once
+  int32_t* tile_ctr;
+  int32_t xcd_mask, xcd_cnt;
 };
 
 // tile-shape selectors of the LDS-DMA bf16 kernels (v2a_set_tuning)
@@ -79,11 +83,10 @@ using v2a_detail::GemmParams;
 // A_bytes * gn + W_bytes * gm (wide outputs: 1 x 8, W read once; narrow ones with long K: 4 x 2 or 2 x 4).  Tiles are
 // numbered rectangle by rectangle (M-fastest inside one, so consecutive workgroups of an XCD share a W panel) and label x takes
 // the x-th contiguous chunk of that order; chunk and rectangle sizes differ by at most a few tiles, which costs locality only.
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int gm, int gn, int& tm, int& tn) {
-  const int nwg = tiles_m * tiles_n;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);      // bijective: position in the linear order
-  for (int rect = 0; rect < 8; ++rect) {
+// position L of the linear tile order (rectangle by rectangle, M-fastest inside one) -> tile coordinates
+__device__ __forceinline__ void tile_of_index(int L, int tiles_m, int tiles_n, int gm, int gn, int& tm, int& tn) {
+  const int nrect = gm * gn;
+  for (int rect = 0; rect < nrect; ++rect) {
     const int xm = rect / gn, xn = rect % gn;
     const int m_lo = xm * tiles_m / gm, m_hi = (xm + 1) * tiles_m / gm;
     const int n_lo = xn * tiles_n / gn, n_hi = (xn + 1) * tiles_n / gn;
@@ -97,6 +100,15 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n,
   }
   tm = tn = 0;   // unreachable: the rectangles tile the space
 }
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int gm, int gn, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);      // bijective: position in the linear order
+  tile_of_index(L, tiles_m, tiles_n, gm, gn, tm, tn);
+}
+
+// XCD-subset placement: the physical XCD of this workgroup (HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7); }
 
 template <typename T> struct TileCfg;
 template <> struct TileCfg<bf16_t> {
