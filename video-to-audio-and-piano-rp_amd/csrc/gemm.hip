@@ -274,35 +274,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
       grow[i] = r < p.N ? r : p.N - 1;
     }
   }
-  int cur_seg = 0;
   set_offsets(p.lda[0]);
-  const char* wbase = reinterpret_cast<const char*>(p.w);
   // K-tile offset table read through the constant address space: a scalar load (lgkmcnt).  As a plain global load inside
   // the K loop it became a VECTOR load (the LDS-DMA stores "clobber" memory for the compiler) followed by s_waitcnt vmcnt(0)
   // -- on the dense path too, at the join of the two branches -- which drained the staged tiles in flight every K tile.
   typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
   const const_i32_ptr koff_tab = (const_i32_ptr)p.a_koff;
 
-  // K rotation: the tiles_m workgroups that share a W panel start their K walk at different K tiles and wrap around.  All of
-  // them walking k = 0, 1, 2 ... together made every K step a first touch of the same W lines -- one HBM round trip per step
-  // for the whole group -- whereas staggered starts pull the panel into L2 from tiles_m places at once and most steps of a
-  // workgroup then hit lines a neighbour already fetched.  (Changes only the fp32 summation order, identically in every run.)
-  const int nk_all = p.K / 64;
-  const int rot = p.krot ? (int)(((int64_t)tm * nk_all) / tiles_m) : 0;
-  auto issue = [&](int kt_seq, int stage) {
-    int kt = kt_seq + rot;
-    kt -= kt >= nk_all ? nk_all : 0;
-    const int k0 = kt * 64;
-    int sgi = 0, kbeg = 0;
-    if (p.nseg > 1 && k0 >= p.kend[0]) { sgi = 1; kbeg = p.kend[0]; }
-    if (p.nseg > 2 && k0 >= p.kend[1]) { sgi = 2; kbeg = p.kend[1]; }
-    if (sgi != cur_seg) {            // at most twice per kernel: the next A segment has its own row stride
-      cur_seg = sgi;
-      set_offsets(p.lda[sgi]);
+  // Operand stream state, all wave-uniform: K tiles are issued strictly in order, so the A / W tile bases are running pointers
+  // stepped by 128 B per K tile and the (at most two) segment switches are counted down.  The first version recomputed the
+  // segment of every K tile from the kernel arguments -- p.a[sgi] / p.lda[sgi] with a run-time sgi are two dependent scalar
+  // loads from the argument segment, plus ~60 scalar and vector-select instructions -- between the barrier and the first DMA of
+  // EVERY K step: ~500 cycles per step for 128 cycles of MFMA on a 64x64 tile (ISA listing and K-loop probe in DESIGN.md section 4).
+  const char* a_run = reinterpret_cast<const char*>(p.a[0]);
+  const char* w_run = reinterpret_cast<const char*>(p.w);
+  const char* const a_first = a_run;
+  const int nseg = p.nseg;
+  int seg = 0;
+  int seg_left = (nseg > 1 ? p.kend[0] : p.K) >> 6;       // K tiles left in the current segment
+  int kt_next = 0;                                        // index of the next K tile to issue (offset-table path only)
+  auto issue = [&](int stage) {
+    if (seg_left == 0) {                                  // at most twice per kernel: the next A segment has its own base and row stride
+      ++seg;
+      a_run = reinterpret_cast<const char*>(seg == 1 ? p.a[1] : p.a[2]);
+      seg_left = (seg == 1 ? (nseg > 2 ? p.kend[1] : p.K) - p.kend[0] : p.K - p.kend[1]) >> 6;
+      set_offsets(seg == 1 ? p.lda[1] : p.lda[2]);
     }
-    const int64_t akoff = koff_tab ? (int64_t)koff_tab[kt] : (int64_t)(k0 - kbeg);       // wave-uniform (scalar load)
-    const char* ab = reinterpret_cast<const char*>(p.a[sgi]) + akoff * 2;
-    const char* wb = wbase + (int64_t)k0 * 2;
+    const char* ab = a_run;
+    if (koff_tab) ab = a_first + (int64_t)koff_tab[kt_next] * 2;     // implicit-GEMM convolution: wave-uniform scalar load
+    const char* wb = w_run;
     char* st = smem_raw + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
@@ -314,6 +314,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + goff[i]),
                                          (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
     }
+    a_run += 128;
+    w_run += 128;
+    --seg_left;
+    ++kt_next;
   };
 
   // epilogue operands are prefetched unless registers are short: the 256x256 tile (128 accumulators per lane) and the
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   // bound by DMA latency x bytes in flight -- a K step of the 3-deep 64x64 ring took 1020 cycles for 128 cycles of MFMA)
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < nk) issue(s0, s0);
+    if (s0 < nk) issue(s0);
   // ... and turned into the row's scale behind them (visible to every wave after the K loop's barriers)
   if (scaled && tid < BM) rs_lds[tid] = rowscale_finish(p, rsl);
   // one K tile; STAGE is a compile-time ring position so every LDS address is base + immediate
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     // tile kt has landed for this wave once only the younger tile's DMAs remain outstanding
     ring_wait<NST - 2 < 0 ? 0 : NST - 2, LPW>(nk - 1 - kt);
     __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1) % NST
-    if (kt + NST - 1 < nk) issue(kt + NST - 1, (STAGE + NST - 1) % NST);
+    if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
     const bf16_t* Ws = As + BM * 64;
     // both 32-wide K halves of the tile are requested before the first MFMA: the second half's LDS latency runs under the
@@ -423,7 +427,9 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
     case V2A_EPI_STORE:
       return out_f32 ? launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST>(p, s) : launch_dma<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
     case V2A_EPI_GEGLU:   // fp32 output: the hidden activation of the bf16x3 mode, split into hi / lo planes afterwards
-      return out_f32 ? launch_dma<V2A_EPI_GEGLU, float, BM, BN, WGM, WGN, NST>(p, s) : launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
+      if constexpr ((BN / WGN / 16) % 2 == 0)
+        return out_f32 ? launch_dma<V2A_EPI_GEGLU, float, BM, BN, WGM, WGN, NST>(p, s) : launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST>(p, s);
+      break;
     case V2A_EPI_RESID:
       if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN, NST>(p, s);
       break;
@@ -440,7 +446,7 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 // (A/B on MI355X: +1..2 % at 8 clips per GPU end to end).  At one clip its 224-280 workgroups of 128 KB LDS take every CU for
 // 35-70 us: alone it is the fastest choice for the feed-forward GEMMs (774 vs 644 TF/s), beside the other two streams of the
 // sampler it costs 1.3 % end to end, and with fewer tiles the 128x256 ring kernel fills the chip better anyway.
-static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400, 1};
+static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400, 1, 0};
 v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 int v2a_detail::g_attn_one_group_from = 1536;
@@ -464,7 +470,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   v2a_detail::g_attn_one_group_from = t->attn_one_group_from > 0 ? t->attn_one_group_from : 1536;
   v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,
                                t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,
-                               t->gemm_xcd_order_1x8 ? 0 : 1};
+                               t->gemm_xcd_order_1x8 ? 0 : 1, t->reserved[0]};
   return V2A_OK;
 }
 
@@ -525,7 +531,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   // off by default: +0.7 % throughput, but the fp32 summation order of a row then depends on how many rows the call has, so a
   // clip's result would change (in the last bits) with the batch it is sampled in; v2a_set_tuning enables it
   const v2a_detail::GemmTuning tune = v2a_detail::g_gemm_tuning;
-  p.krot = tune.krot;
+  p.krot = 0;
+  p.dbg = tune.dbg;
   {
     // XCD grid over the tile space: minimise A_bytes * gn + W_bytes * gm (gemm_common.h, tile_of_block); v2a_set_tuning can
     // pin the old 1 x 8 order for A/B measurements
@@ -622,7 +629,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   // bf16 x bf16: LDS-DMA kernel; tile shape by how many workgroups the problem yields (256 CUs)
   auto ntiles = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
   // wide outputs: 256x256 tile with the phase-interleaved K loop (gemm_8phase.hip) once the problem yields enough tiles
-  V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 9, "v2a_gemm: tile_hint %d", a->tile_hint);
+  V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 16, "v2a_gemm: tile_hint %d", a->tile_hint);
   const bool dense = !a->a_row_offset && !a->out_row_offset && p.vec_epi;
   if (a->tile_hint > 0 && tune.force_tile < 0) {
     if (a->tile_hint == 7) {
@@ -636,6 +643,13 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
       case 2: return dispatch_dma<128, 64, 2, 2>(a, p, s);
       case 7: return dispatch_dma<64, 128, 2, 2, 6>(a, p, s);
       case 8: return dispatch_dma<64, 64, 2, 2, 6>(a, p, s);
+      case 9: return dispatch_dma<64, 64, 2, 2, 4>(a, p, s);
+      case 10: return dispatch_dma<64, 64, 2, 2, 5>(a, p, s);
+      case 11: return dispatch_dma<128, 128, 2, 2, 4>(a, p, s);
+      case 12: return dispatch_dma<128, 128, 2, 4, 3>(a, p, s);   // 8 waves (two per SIMD), wave tile 64x32
+      case 13: return dispatch_dma<64, 64, 2, 4, 3>(a, p, s);     // 8 waves, wave tile 32x16 (no GEGLU)
+      case 14: return dispatch_dma<128, 64, 4, 2, 3>(a, p, s);    // 8 waves, wave tile 32x32
+      case 15: return dispatch_dma<64, 128, 2, 4, 3>(a, p, s);    // 8 waves, wave tile 32x32
       default: return dispatch_dma<64, 64, 2, 2>(a, p, s);
     }
   }

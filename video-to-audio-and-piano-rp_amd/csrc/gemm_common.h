@@ -53,6 +53,7 @@ struct GemmParams {
   // tiles of that XCD's chunk through a device counter, the others leave at once
   int32_t* tile_ctr;
   int32_t xcd_mask, xcd_cnt;
+  int32_t dbg;              // probe builds only (-DV2A_GEMM_PROBE, scripts/probes/kloop_probe.py): K-loop parts switched off by bit
 };
 
 // tile-shape selectors of the LDS-DMA bf16 kernels (v2a_set_tuning)
@@ -62,6 +63,7 @@ struct GemmTuning {
   int use_8phase;        // 256x256 8-phase kernel for wide outputs: 0 off, 1 staggered wave rows, 2 lock-step
   int min_tiles_8phase;  // ... when the problem has at least this many 256x256 tiles
   int xcd_grid;          // 1: XCD rectangle grid chosen per shape, 0: always 1 x 8 (every XCD walks all M of its column strip)
+  int dbg;               // probe builds only: v2a_tuning.reserved[0]
 };
 extern GemmTuning g_gemm_tuning;
 extern int g_attn_one_group_from;    // v2a_attention: workgroup count from which one wave group per workgroup is used
