@@ -634,6 +634,87 @@ def test_cross_condition_vs_reference_module(L, intree, flag):
 
 
 # ------------------------------------------------------------------------ split-bf16 ("bf16x3") building blocks
+def _split_planes(x):
+    """fp32 (rows, k) -> bf16 (rows, 2k) = [hi | lo] (the V2A_BF16_SPLIT layout)."""
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    return torch.cat([hi, lo], -1).contiguous()
+
+
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("epi", ["store", "resid_shadow", "gate_norm", "geglu"])
+@pytest.mark.parametrize("M,N,ks", [(300, 192, (256,)), (1564, 1024, (1024, 1280, 512)), (782, 1280, (1024, 1280)), (130, 2048, (512,))])
+def test_gemm_split_native(L, hint, epi, M, N, ks):
+    """v2a_gemm with a_dtype V2A_BF16_SPLIT: A segments as [hi | lo] rows, W as [W_hi | W_lo], acc = A_lo W_hi + A_hi W_lo + A_hi W_hi
+    in ONE launch over up to three logical K segments (TextAudioCrossCondition's pack, x3:693-700), every epilogue of the bf16x3
+    mode: fp32 store, residual + split (hi | lo) shadow, gated residual + folded-norm producer with a split shadow, GEGLU with
+    split output.  Against the fp64 product: ~1e-5 relative (three bf16 MFMA products per fp32 product)."""
+    g = _g(M + N + len(ks))
+    K = sum(ks)
+    a = [torch.randn(M, k, generator=g) for k in ks]
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    segs = [(_split_planes(x).to(DEV), 2 * k, k) for x, k in zip(a, ks)]
+    wd = torch.cat([w.bfloat16(), (w - w.bfloat16().float()).bfloat16()], 1).contiguous().to(DEV)          # [W_hi | W_lo]
+    bias = (0.1 * torch.randn(N, generator=g))
+    acc = torch.cat(a, 1).double() @ w.double().t()
+    kw = dict(M=M, N=N, compute=L.BF16, a_split=True, tile_hint=hint)
+    scale = float(acc.abs().max())
+    if epi == "store":
+        out = torch.empty(M, N, device=DEV)
+        L.gemm(segs, wd, out, bias=bias.to(DEV), **kw)
+        err = float((out.cpu().double() - (acc + bias.double())).abs().max())
+        assert err < 3e-5 * max(scale, 1.0), err
+    elif epi == "resid_shadow":
+        res = torch.randn(M, N, generator=g)
+        out, sh = torch.empty(M, N, device=DEV), torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=DEV)
+        L.gemm(segs, wd, out, epilogue=L.EPI_RESID, resid=res.to(DEV), out_bf16=sh, ld_out_bf16=2 * N, out_bf16_split=True, **kw)
+        ref = res.double() + acc
+        assert float((out.cpu().double() - ref).abs().max()) < 3e-5 * max(scale, 1.0)
+        assert torch.equal(sh.cpu(), _split_planes(out.cpu()))
+    elif epi == "gate_norm":
+        res = torch.randn(M, N, generator=g)
+        gate, gam = torch.rand(N, generator=g), 1 + 0.2 * torch.randn(N, generator=g)
+        out = res.clone().to(DEV)
+        sh, ssq = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=DEV), torch.zeros(M, N // 32, device=DEV)
+        L.gemm(segs, wd, out, epilogue=L.EPI_GATE_RESID, resid=out, gate=gate.to(DEV), bias=bias.to(DEV), out_bf16=sh, ld_out_bf16=2 * N,
+               out_bf16_split=True, norm_gamma=gam.to(DEV), norm_ssq=ssq, **kw)
+        ref = res.double() + gate.double() * (acc + bias.double())
+        assert float((out.cpu().double() - ref).abs().max()) < 3e-5 * max(scale, 1.0)
+        assert torch.equal(sh.cpu(), _split_planes(out.cpu() * gam))
+        torch.testing.assert_close(ssq.cpu().double(), (out.cpu().double() ** 2).reshape(M, N // 32, 32).sum(-1), rtol=1e-5, atol=1e-6)
+    else:
+        # GEGLU: W rows regrouped [16 value | 16 gate]; output hi | lo planes of the N / 2 hidden values, exact erf GELU
+        half = N // 2
+        perm = torch.cat([torch.cat([torch.arange(j * 16, j * 16 + 16), half + torch.arange(j * 16, j * 16 + 16)]) for j in range(half // 16)])
+        wp, bp = w[perm], bias[perm]
+        wpd = torch.cat([wp.bfloat16(), (wp - wp.bfloat16().float()).bfloat16()], 1).contiguous().to(DEV)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        L.gemm(segs, wpd, out, epilogue=L.EPI_GEGLU, bias=bp.to(DEV), ldo=N, out_split=True, **kw)
+        z = acc + bias.double()
+        ref = z[:, :half] * torch.nn.functional.gelu(z[:, half:])
+        got = out[:, :half].float().cpu().double() + out[:, half:].float().cpu().double()
+        err = float((got - ref).abs().max())
+        assert err < 4e-5 * max(float(ref.abs().max()), 1.0), err
+
+
+def test_gemm_split_native_folded_norm_consumer(L):
+    """... and as the CONSUMER of a folded RMSNorm: A = split(x * gamma), the accumulator row scaled by sqrt(d) / |x| before the bias."""
+    M, K, N = 300, 512, 256
+    g = _g(77)
+    x = torch.randn(M, K, generator=g) * 3
+    gam = 1 + 0.2 * torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = 0.1 * torch.randn(N, generator=g)
+    ssq = (x.double() ** 2).reshape(M, K // 32, 32).sum(-1).float()
+    wd = torch.cat([w.bfloat16(), (w - w.bfloat16().float()).bfloat16()], 1).contiguous().to(DEV)
+    out = torch.empty(M, N, device=DEV)
+    L.gemm([(_split_planes(x * gam).to(DEV), 2 * K, K)], wd, out, M=M, N=N, compute=L.BF16, a_split=True, bias=bias.to(DEV),
+           row_ssq=ssq.to(DEV), row_norm_dim=K)
+    xn = torch.nn.functional.normalize(x.double(), dim=-1) * math.sqrt(K) * gam.double()
+    ref = xn @ w.double().t() + bias.double()
+    assert float((out.cpu().double() - ref).abs().max()) < 5e-5 * float(ref.abs().max())
+
+
 def test_split_bf16_planes_and_three_segment_gemm(L):
     """v2a_split_bf16 / rmsnorm(split) write hi | lo planes; the three-segment GEMM [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]^T
     reproduces the fp32 product to ~1e-5 relative (bf16 alone: ~1e-2)."""

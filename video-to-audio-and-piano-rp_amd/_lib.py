@@ -282,8 +282,10 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
          a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0,
          norm_gamma=None, norm_step_stride=0, norm_batch_stride=0, norm_switch_row=0, norm_switch_offset=0, norm_ssq=None,
-         row_ssq=None, row_norm_dim=0, xcd_mask=0, tile_counters=None, out_bf16_split=False):
+         row_ssq=None, row_norm_dim=0, xcd_mask=0, tile_counters=None, out_bf16_split=False, a_split=False, out_split=False):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype.
+    a_split: the segments are V2A_BF16_SPLIT rows ([hi k | lo k], lda >= 2k) and w is [N][2K] = [W_hi | W_lo] (the bf16x3 mode's native
+    GEMM: three MFMA products per fp32 product); out_split: GEGLU output as hi | lo planes; out_bf16_split: the shadow likewise.
     Folded RMSNorm (v2a_gemm_args): producer -- norm_gamma (+ strides / switch) scales the out_bf16 shadow, norm_ssq (rows, N/32)
     receives the sums of squares; consumer -- row_ssq (rows, parts) of its A rows and row_norm_dim = their width."""
     g = GemmArgs()
@@ -292,7 +294,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
         g.lda[i] = lda
         g.ka[i] = k
     g.nseg = len(a_segs)
-    g.a_dtype = dt_code(a_segs[0][0].dtype)
+    g.a_dtype = BF16_SPLIT if a_split else dt_code(a_segs[0][0].dtype)
     g.w = w.data_ptr()
     g.ldw = w.stride(0)
     g.bias = _p(bias)
@@ -301,7 +303,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.epilogue = epilogue
     g.out = out.data_ptr()
     g.ldo = ldo if ldo is not None else out.stride(-2)
-    g.out_dtype = dt_code(out.dtype)
+    g.out_dtype = BF16_SPLIT if out_split else dt_code(out.dtype)
     g.out_bf16 = _p(out_bf16)
     g.ld_out_bf16 = (ld_out_bf16 if ld_out_bf16 is not None else g.ldo) if out_bf16 is not None else 0
     g.resid = _p(resid)
@@ -315,7 +317,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
     g.relu = 1 if relu else 0
     g.a_row_offset, g.a_ktile_offset, g.out_row_offset = _p(a_row_offset), _p(a_ktile_offset), _p(out_row_offset)
-    g.tile_hint = tile_hint if compute == BF16 and g.a_dtype == BF16 and epilogue != EPI_SIGMOID else 0
+    g.tile_hint = tile_hint if compute == BF16 and g.a_dtype in (BF16, BF16_SPLIT) and epilogue != EPI_SIGMOID else 0
     g.norm_gamma = _p(norm_gamma)
     g.norm_step_stride, g.norm_batch_stride = norm_step_stride, norm_batch_stride
     g.norm_switch_row, g.norm_switch_offset = norm_switch_row, norm_switch_offset
@@ -328,7 +330,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
     g.tile_counters, g.xcd_mask = _p(tile_counters), xcd_mask
     g.out_bf16_split = 1 if out_bf16_split else 0
     K = sum(k for _, _, k in a_segs)
-    key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else "a_bf16",
+    key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else ("a_split" if a_split else "a_bf16"),
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
     esz = 2 if compute == BF16 else 4
     nbytes = M * K * (4 if g.a_dtype == F32 else 2) + N * K * esz + M * (N // 2 if epilogue == EPI_GEGLU else N) * out.element_size()
@@ -336,7 +338,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
         key = key[:-1] + ",tile%d>" % (g.tile_hint - 1)        # side-stream launches: tile shape chosen for running beside others
     if _prof is not None and _prof.shapes:
         key += " %dx%dx%d" % (M, N, K)
-    _launch(key, 2.0 * M * N * K, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
+    _launch(key, (6.0 if a_split else 2.0) * M * N * K, nbytes * (2 if a_split else 1), lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
 
 
 def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch_stride=0, rows_per_batch=0,

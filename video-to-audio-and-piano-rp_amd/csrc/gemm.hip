@@ -185,12 +185,18 @@ __device__ __forceinline__ void ring_wait(int younger) {
   }
 }
 
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3>
+// S3 (the "bf16x3" mode natively): both operands arrive as hi | lo bf16 planes (V2A_BF16_SPLIT rows of A, W rows [W_hi | W_lo]),
+// a ring stage holds the four plane tiles of a K step and every fragment pair feeds three MFMAs,
+//   acc += A_lo W_hi + A_hi W_lo + A_hi W_hi   (fp32-grade product, relative error ~2^-16),
+// so a K step moves 2x the bytes of a bf16 step for 3x its flops -- where the three-segment form on the plain kernel
+// ([A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]) moved 3x the bytes and needed one launch per logical K segment.
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int PLANE_BYTES = (BM + BN) * 128;            // one A tile + one W tile of a K step
+  constexpr int STAGE_BYTES = PLANE_BYTES * (S3 ? 2 : 1); // S3: [A_hi | W_hi | A_lo | W_lo]
   constexpr int GA = BM / 8, GW = BN / 8;       // 8-row DMA groups of the A and W tiles
   constexpr int LPW = (GA + GW) / NW;           // DMA instructions per wave per K tile
   static_assert((GA + GW) % NW == 0, "DMA groups must divide evenly over the waves");
@@ -203,8 +209,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 15, lq = lane >> 4;
 
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = p.tiles_n, tiles_m = p.tiles_m;
   int tm, tn;
   if (p.tile_ctr) {
     // XCD-subset placement: one lane asks which XCD the workgroup landed on; on an XCD of the mask it claims the next tile of that
@@ -235,9 +240,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     __syncthreads();
     const int L = __builtin_amdgcn_readfirstlane(*slot);
     if (L < 0) return;
-    tile_of_index(L, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
+    tile_of_index(p, L, tm, tn);
   } else {
-    tile_of_block(blockIdx.x, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
+    tile_of_block(p, blockIdx.x, tm, tn);
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -292,12 +297,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   const int nseg = p.nseg;
   int seg = 0;
   int seg_left = (nseg > 1 ? p.kend[0] : p.K) >> 6;       // K tiles left in the current segment
+  // S3: byte offset of the lo plane inside an A row (= the segment's K extent) and inside a W row (= K)
+  int64_t a_lo_bytes = S3 ? (int64_t)(nseg > 1 ? p.kend[0] : p.K) * 2 : 0;
+  const int64_t w_lo_bytes = S3 ? (int64_t)p.K * 2 : 0;
   int kt_next = 0;                                        // index of the next K tile to issue (offset-table path only)
   auto issue = [&](int stage) {
     if (seg_left == 0) {                                  // at most twice per kernel: the next A segment has its own base and row stride
       ++seg;
       a_run = reinterpret_cast<const char*>(seg == 1 ? p.a[1] : p.a[2]);
       seg_left = (seg == 1 ? (nseg > 2 ? p.kend[1] : p.K) - p.kend[0] : p.K - p.kend[1]) >> 6;
+      if constexpr (S3) a_lo_bytes = (int64_t)seg_left * 128;
       set_offsets(seg == 1 ? p.lda[1] : p.lda[2]);
     }
     const char* ab = a_run;
@@ -313,6 +322,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
       else
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + goff[i]),
                                          (__attribute__((address_space(3))) void*)(st + g * 1024), 16, 0, 0);
+    }
+    if constexpr (S3) {          // the lo planes: same rows, the segment's / the weight's plane offset further
+#pragma unroll
+      for (int i = 0; i < LPW; ++i) {
+        const int g = wave + i * NW;
+        if (g < GA)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + a_lo_bytes + goff[i]),
+                                           (__attribute__((address_space(3))) void*)(st + PLANE_BYTES + g * 1024), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + w_lo_bytes + goff[i]),
+                                           (__attribute__((address_space(3))) void*)(st + PLANE_BYTES + g * 1024), 16, 0, 0);
+      }
     }
     a_run += 128;
     w_run += 128;
@@ -344,9 +365,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   auto tile = [&](auto stage_c, int kt) {
     constexpr int STAGE = decltype(stage_c)::value;
     // tile kt has landed for this wave once only the younger tile's DMAs remain outstanding
-    ring_wait<NST - 2 < 0 ? 0 : NST - 2, LPW>(nk - 1 - kt);
+    ring_wait<NST - 2 < 0 ? 0 : NST - 2, LPW * (S3 ? 2 : 1)>(nk - 1 - kt);
     __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1) % NST
-    if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
     const bf16_t* Ws = As + BM * 64;
     // both 32-wide K halves of the tile are requested before the first MFMA: the second half's LDS latency runs under the
@@ -365,6 +385,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
         bf[kk][j] = *reinterpret_cast<const bf16x8*>(Ws + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
       }
     }
+    if constexpr (S3) {
+      // lo planes of the same rows; three products per fragment pair, small terms first
+      const bf16_t* Al = As + PLANE_BYTES / 2;
+      const bf16_t* Wl = Al + BM * 64;
+      bf16x8 afl[2][TM], bfl[2][TN];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * WM + i * 16 + lr;
+          afl[kk][i] = *reinterpret_cast<const bf16x8*>(Al + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wn * WN + j * 16 + lr;
+          bfl[kk][j] = *reinterpret_cast<const bf16x8*>(Wl + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+        }
+      }
+      if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfl[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+          }
+    } else {
+    // the next tile's DMA is issued behind the first half's fragment reads: their LDS latency runs under the DMA issue
+    // (~4 x LPW scalar instructions and LPW address translations) instead of after it
+    if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -373,16 +426,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
     // pin that order (the scheduler otherwise sinks the second half's reads back below the first MFMA cluster):
-    // [first half's reads] then {a few MFMAs, one read of the second half} ... then the remaining MFMAs
+    // [first half's reads] [the DMA issue] then {a few MFMAs, one read of the second half} ... then the remaining MFMAs
     {
       constexpr int NL = TM + TN, NM = TM * TN, PER = NM / NL > 0 ? NM / NL : 1;
       __builtin_amdgcn_sched_group_barrier(0x100, NL, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, LPW, 0);
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - PER * NL, 0);
+    }
     }
   };
   static_assert(NST >= 2 && NST <= 6, "ring depth");
@@ -404,16 +459,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
   }
 }
 
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST>
-int launch_dma(const GemmParams& p, hipStream_t s) {
-  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 + BM * 4 + 16;    // the ring + one row scale per tile row (folded RMSNorm) + the claimed tile
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST, bool S3 = false>
+int launch_dma(const GemmParams& p_in, hipStream_t s) {
+  GemmParams p = p_in;
+  v2a_detail::fill_tile_map(p, BM, BN);
+  V2A_REQUIRE((int64_t)p.tiles_m * p.tiles_n < (1 << 24), "v2a_gemm: %d x %d tiles exceed the tile map", p.tiles_m, p.tiles_n);
+  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 * (S3 ? 2 : 1) + BM * 4 + 16;    // the ring + one row scale per tile row (folded RMSNorm) + the claimed tile
+  static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
   int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   // XCD-subset placement: workgroups are dealt round-robin over the 8 XCDs, so 8 * ceil(tiles / XCDs in the mask) of them put
   // enough on every XCD of the mask to claim its chunk; the rest leave at once
   if (p.tile_ctr) tiles = 8 * ((tiles + p.xcd_cnt - 1) / p.xcd_cnt);
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
-  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST>;
+  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3>;
   static std::atomic<uint64_t> lds_set{0};
   if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm(dma)")) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WGM * WGN), smem, s, p);
@@ -438,6 +497,29 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
       break;
   }
   return v2a_fail(V2A_ERR_ARG, "v2a_gemm(dma): unsupported epilogue %d / out_dtype %d", a->epilogue, a->out_dtype);
+}
+
+// split-bf16 operands (bf16x3 mode): the epilogues that mode uses
+template <int BM, int BN, int WGM, int WGN, int NST>
+int dispatch_s3(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
+  const bool out_f32 = a->out_dtype == V2A_F32;
+  switch (a->epilogue) {
+    case V2A_EPI_STORE:
+      if (out_f32) return launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST, true>(p, s);
+      break;
+    case V2A_EPI_GEGLU:
+      if constexpr ((BN / WGN / 16) % 2 == 0) {
+        if (a->out_dtype == V2A_BF16_SPLIT) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST, true>(p, s);
+      }
+      break;
+    case V2A_EPI_RESID:
+      if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN, NST, true>(p, s);
+      break;
+    case V2A_EPI_GATE_RESID:
+      if (out_f32) return launch_dma<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST, true>(p, s);
+      break;
+  }
+  return v2a_fail(V2A_ERR_ARG, "v2a_gemm(split bf16): unsupported epilogue %d / out_dtype %d for this tile shape", a->epilogue, a->out_dtype);
 }
 
 }  // namespace
@@ -479,24 +561,26 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   V2A_REQUIRE(a->nseg >= 1 && a->nseg <= 3, "v2a_gemm: nseg=%d", a->nseg);
   V2A_REQUIRE(a->M > 0 && a->N > 0, "v2a_gemm: M=%d N=%d", a->M, a->N);
   V2A_REQUIRE(a->compute_dtype == V2A_F32 || a->compute_dtype == V2A_BF16, "v2a_gemm: compute dtype %d", a->compute_dtype);
-  V2A_REQUIRE(a->a_dtype == a->compute_dtype || a->a_dtype == V2A_F32, "v2a_gemm: A dtype %d with compute dtype %d",
-              a->a_dtype, a->compute_dtype);
+  const bool split_in = a->a_dtype == V2A_BF16_SPLIT;   // A rows and W rows as hi | lo bf16 planes: three MFMA products per fp32 product
+  V2A_REQUIRE(a->a_dtype == a->compute_dtype || a->a_dtype == V2A_F32 || (split_in && a->compute_dtype == V2A_BF16),
+              "v2a_gemm: A dtype %d with compute dtype %d", a->a_dtype, a->compute_dtype);
   const int bk = a->compute_dtype == V2A_BF16 ? 64 : 16;
-  const int a_vec = a->a_dtype == V2A_BF16 ? 8 : 4;  // elements per 16-byte load
+  const int a_vec = a->a_dtype == V2A_F32 ? 4 : 8;  // elements per 16-byte load
   GemmParams p{};
   int K = 0;
   for (int s = 0; s < a->nseg; ++s) {
     V2A_REQUIRE(a->a[s] != nullptr, "v2a_gemm: segment %d null", s);
     V2A_REQUIRE(a->ka[s] > 0 && a->ka[s] % bk == 0, "v2a_gemm: segment %d K=%d not a multiple of %d", s, a->ka[s], bk);
     V2A_REQUIRE(a->lda[s] % a_vec == 0 && ((uintptr_t)a->a[s] & 15) == 0, "v2a_gemm: segment %d not 16-byte aligned", s);
+    if (split_in) V2A_REQUIRE(a->lda[s] >= 2 * (int64_t)a->ka[s], "v2a_gemm: split segment %d needs lda >= 2 * K (hi | lo planes)", s);
     p.a[s] = a->a[s];
     p.lda[s] = a->lda[s];
     K += a->ka[s];
     p.kend[s] = K;
   }
   p.nseg = a->nseg;
-  V2A_REQUIRE(a->w != nullptr && ((uintptr_t)a->w & 15) == 0 && a->ldw % (a->compute_dtype == V2A_BF16 ? 8 : 4) == 0 && a->ldw >= K,
-              "v2a_gemm: W pointer/ldw (%lld) misaligned or < K=%d", (long long)a->ldw, K);
+  V2A_REQUIRE(a->w != nullptr && ((uintptr_t)a->w & 15) == 0 && a->ldw % (a->compute_dtype == V2A_BF16 ? 8 : 4) == 0 && a->ldw >= (split_in ? 2 : 1) * (int64_t)K,
+              "v2a_gemm: W pointer/ldw (%lld) misaligned or < K=%d (x2 for split operands)", (long long)a->ldw, K);
   V2A_REQUIRE(a->out != nullptr, "v2a_gemm: out null");
   p.w = a->w;
   p.ldw = a->ldw;
@@ -509,6 +593,10 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   p.out2 = reinterpret_cast<bf16_t*>(a->out_bf16);
   p.ldo2 = a->ld_out_bf16;
   if (a->out_bf16) V2A_REQUIRE(a->out_dtype == V2A_F32 && a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: out_bf16 shadows an fp32 output only");
+  p.out2_split = a->out_bf16 && a->out_bf16_split ? 1 : 0;
+  if (p.out2_split) V2A_REQUIRE(a->ld_out_bf16 >= 2 * (int64_t)a->N, "v2a_gemm: a split shadow needs ld_out_bf16 >= 2 * N");
+  p.out_split = a->out_dtype == V2A_BF16_SPLIT ? 1 : 0;
+  if (p.out_split) V2A_REQUIRE(a->epilogue == V2A_EPI_GEGLU && a->ldo >= a->N, "v2a_gemm: out_dtype V2A_BF16_SPLIT goes with the GEGLU epilogue and ldo >= N");
   p.resid = a->resid;
   p.ldr = a->ldr;
   p.gate = a->gate;
@@ -518,7 +606,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : a->M;
   {
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const int osz = a->out_dtype == V2A_F32 ? 4 : 2;
+    const int osz = a->out_dtype == V2A_F32 ? 4 : 2;      // V2A_BF16 and V2A_BF16_SPLIT: bf16 elements
     const int ncols = a->epilogue == V2A_EPI_GEGLU ? a->N / 2 : a->N;
     bool ok = a->N % 4 == 0 && ncols % 4 == 0 && ((uintptr_t)a->out % (4 * osz)) == 0 && (a->ldo * osz) % (4 * osz) == 0;
     if (a->bias) ok = ok && al16(a->bias);
@@ -590,8 +678,8 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   p.rssq_parts = a->row_ssq_parts;
   p.rnorm = sqrtf((float)a->row_norm_dim);
   if (a->norm_gamma || a->norm_ssq || a->row_ssq) {
-    V2A_REQUIRE(a->compute_dtype == V2A_BF16 && a->a_dtype == V2A_BF16 && p.vec_epi && a->epilogue != V2A_EPI_SIGMOID && !a->out_row_offset,
-                "v2a_gemm: a folded RMSNorm needs bf16 x bf16 operands, dense rows and 16-byte aligned epilogue operands");
+    V2A_REQUIRE(a->compute_dtype == V2A_BF16 && (a->a_dtype == V2A_BF16 || split_in) && p.vec_epi && a->epilogue != V2A_EPI_SIGMOID && !a->out_row_offset,
+                "v2a_gemm: a folded RMSNorm needs bf16 x bf16 (or split bf16) operands, dense rows and 16-byte aligned epilogue operands");
     if (a->norm_gamma || a->norm_ssq)
       V2A_REQUIRE(a->out_bf16 && (a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID) && a->N % 32 == 0 &&
                       (!a->norm_gamma || (((uintptr_t)a->norm_gamma & 15) == 0 && a->norm_step_stride % 4 == 0 && a->norm_batch_stride % 4 == 0 &&
@@ -608,7 +696,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   p.rope_cols = a->rope_cols;
   p.rope_pos_off = a->rope_pos_offset;
   if (a->rope_table) {
-    V2A_REQUIRE(a->epilogue == V2A_EPI_STORE && a->compute_dtype == V2A_BF16 && a->a_dtype == V2A_BF16 && p.vec_epi &&
+    V2A_REQUIRE(a->epilogue == V2A_EPI_STORE && a->compute_dtype == V2A_BF16 && (a->a_dtype == V2A_BF16 || split_in) && p.vec_epi &&
                     a->rope_cols % 64 == 0 && a->rope_cols <= a->N && ((uintptr_t)a->rope_table & 15) == 0,
                 "v2a_gemm: fused RoPE needs the bf16 STORE epilogue with 16-byte aligned rows and rope_cols %% 64 == 0");
   }
@@ -623,6 +711,24 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     const int64_t t128 = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128);
     if (t128 < 224 && a->M > 64) return dispatch_epi<float, false, 64, 64>(a, p, s);
     return dispatch_epi<float, false, 128, 128>(a, p, s);
+  }
+  if (split_in) {
+    V2A_REQUIRE(p.vec_epi && !a->a_row_offset && !a->out_row_offset, "v2a_gemm: split operands need dense rows and 16-byte aligned epilogue operands");
+    V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 4, "v2a_gemm: tile_hint %d with split operands (0 = by shape, 1..4)", a->tile_hint);
+    auto nt = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
+    // split-operand tile shapes (hi + lo planes double a stage): 1 = 64x64 (96 KB), 2 = 128x64 (144 KB), 3 = 128x128 with 8 waves and a
+    // 2-deep ring (128 KB), 4 = 64x128 with 8 waves (144 KB)
+    int cfg = a->tile_hint;
+    if (cfg == 0) {
+      if (a->epilogue == V2A_EPI_GEGLU || a->N >= 2048) cfg = nt(128, 128) >= 200 ? 3 : 4;
+      else cfg = nt(64, 128) >= 160 ? 4 : 1;
+    }
+    switch (cfg) {
+      case 1: return dispatch_s3<64, 64, 2, 2, 3>(a, p, s);
+      case 2: return dispatch_s3<128, 64, 2, 2, 3>(a, p, s);
+      case 3: return dispatch_s3<128, 128, 2, 4, 2>(a, p, s);
+      default: return dispatch_s3<64, 128, 2, 4, 3>(a, p, s);
+    }
   }
   if (a->a_dtype == V2A_F32) return dispatch_epi<bf16_t, true, 128, 128>(a, p, s);
   if (a->epilogue == V2A_EPI_SIGMOID) return dispatch_epi<bf16_t, false, 128, 128>(a, p, s);

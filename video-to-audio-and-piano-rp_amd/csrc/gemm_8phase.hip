@@ -40,10 +40,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;      // waves w and w + 4 (same wc) share a SIMD
   const int lr = lane & 15, lq = lane >> 4;
 
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
   int tm, tn;
-  tile_of_block(blockIdx.x, tiles_m, tiles_n, p.xcd_gm, p.xcd_gn, tm, tn);
+  tile_of_block(p, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[TM][TN];
@@ -224,7 +222,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
 }
 
 template <int EPI, typename OutT>
-int launch_8ph(const GemmParams& p, hipStream_t s) {
+int launch_8ph(const GemmParams& p_in, hipStream_t s) {
+  GemmParams p = p_in;
+  v2a_detail::fill_tile_map(p, 256, 256);
   constexpr size_t smem = 2 * 4 * 128 * 128 + 256 * 4;     // two buffers of four half tiles + one row scale per tile row (folded RMSNorm)
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   const bool stagger = v2a_detail::g_gemm_tuning.use_8phase != 2;

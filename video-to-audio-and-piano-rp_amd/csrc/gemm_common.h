@@ -53,6 +53,14 @@ struct GemmParams {
   // tiles of that XCD's chunk through a device counter, the others leave at once
   int32_t* tile_ctr;
   int32_t xcd_mask, xcd_cnt;
+  // the rectangles of the tile order, filled on the host once the tile shape is known (fill_tile_map): first tile, height and
+  // tile count of each, and 1 / height so that the workgroup's tile costs one multiply and a correction instead of ~40 integer
+  // divisions at the head of every kernel
+  struct Rect { int32_t m_lo, n_lo, cnt, hm; float rcp; } rect[8];
+  int32_t nrect, tiles_m, tiles_n;
+  // split (hi | lo plane) outputs of the bf16x3 mode: out2 = the shadow (lo plane N columns after hi), out = the GEGLU hidden
+  // (lo plane N / 2 columns after hi)
+  int32_t out2_split, out_split;
   int32_t dbg;              // probe builds only (-DV2A_GEMM_PROBE, scripts/probes/kloop_probe.py): K-loop parts switched off by bit
 };
 
@@ -72,6 +80,25 @@ extern int g_dwconv_rows_per_wave;   // 4 or 8 (v2a_set_tuning)
 // 256x256 8-phase kernel (gemm_8phase.hip)
 int launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
 
+// host: the gm x gn rectangles of the tile space for a BM x BN tile shape (xcd_gm / xcd_gn chosen by v2a_gemm)
+inline void fill_tile_map(GemmParams& p, int BM, int BN) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int gm = p.xcd_gm, gn = p.xcd_gn;
+  p.nrect = gm * gn;
+  for (int r = 0; r < p.nrect; ++r) {
+    const int xm = r / gn, xn = r % gn;
+    const int m_lo = xm * p.tiles_m / gm, m_hi = (xm + 1) * p.tiles_m / gm;
+    const int n_lo = xn * p.tiles_n / gn, n_hi = (xn + 1) * p.tiles_n / gn;
+    const int hm = m_hi - m_lo;
+    p.rect[r].m_lo = m_lo;
+    p.rect[r].n_lo = n_lo;
+    p.rect[r].cnt = hm * (n_hi - n_lo);
+    p.rect[r].hm = hm > 0 ? hm : 1;
+    p.rect[r].rcp = 1.0f / (float)(hm > 0 ? hm : 1);
+  }
+}
+
 }  // namespace v2a_detail
 
 namespace {
@@ -86,27 +113,30 @@ using v2a_detail::GemmParams;
 // numbered rectangle by rectangle (M-fastest inside one, so consecutive workgroups of an XCD share a W panel) and label x takes
 // the x-th contiguous chunk of that order; chunk and rectangle sizes differ by at most a few tiles, which costs locality only.
 // position L of the linear tile order (rectangle by rectangle, M-fastest inside one) -> tile coordinates
-__device__ __forceinline__ void tile_of_index(int L, int tiles_m, int tiles_n, int gm, int gn, int& tm, int& tn) {
-  const int nrect = gm * gn;
-  for (int rect = 0; rect < nrect; ++rect) {
-    const int xm = rect / gn, xn = rect % gn;
-    const int m_lo = xm * tiles_m / gm, m_hi = (xm + 1) * tiles_m / gm;
-    const int n_lo = xn * tiles_n / gn, n_hi = (xn + 1) * tiles_n / gn;
-    const int hm = m_hi - m_lo, cnt = hm * (n_hi - n_lo);
-    if (L < cnt) {
-      tn = n_lo + L / hm;
-      tm = m_lo + L % hm;
-      return;
+__device__ __forceinline__ void tile_of_index(const GemmParams& p, int L, int& tm, int& tn) {
+  tm = tn = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (r < p.nrect) {
+      const int cnt = p.rect[r].cnt;
+      if (L >= 0 && L < cnt) {
+        const int hm = p.rect[r].hm;
+        int q = (int)((float)L * p.rect[r].rcp);           // L / hm within one for L < 2^24 (checked on the host), corrected below
+        int rem = L - q * hm;
+        if (rem < 0) { --q; rem += hm; }
+        else if (rem >= hm) { ++q; rem -= hm; }
+        tn = p.rect[r].n_lo + q;
+        tm = p.rect[r].m_lo + rem;
+      }
+      L -= cnt;          // negative from the containing rectangle on: no later one matches
     }
-    L -= cnt;
   }
-  tm = tn = 0;   // unreachable: the rectangles tile the space
 }
-__device__ __forceinline__ void tile_of_block(int bid, int tiles_m, int tiles_n, int gm, int gn, int& tm, int& tn) {
-  const int nwg = tiles_m * tiles_n;
+__device__ __forceinline__ void tile_of_block(const GemmParams& p, int bid, int& tm, int& tn) {
+  const int nwg = p.tiles_m * p.tiles_n;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);      // bijective: position in the linear order
-  tile_of_index(L, tiles_m, tiles_n, gm, gn, tm, tn);
+  tile_of_index(p, L, tm, tn);
 }
 
 // XCD-subset placement: the physical XCD of this workgroup (HW_REG_XCC_ID, bits 3:0)
@@ -398,10 +428,23 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         }
         OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
         if constexpr (sizeof(OutT) == 2) {
-          bf16x4 o;
+          if (p.out_split) {
+            // bf16x3 mode: exact erf GELU in fp32, stored as hi | lo planes (lo plane N / 2 columns further)
+            bf16x4 hi, lo;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[e] + bv[e]) * gelu_fast_f(g[e] + bg[e]));
-          *reinterpret_cast<bf16x4*>(dst) = o;
+            for (int e = 0; e < 4; ++e) {
+              const float o32 = (v[e] + bv[e]) * gelu_erf_f(g[e] + bg[e]);
+              hi[e] = (bf16_t)o32;
+              lo[e] = (bf16_t)(o32 - (float)hi[e]);
+            }
+            *reinterpret_cast<bf16x4*>(dst) = hi;
+            *reinterpret_cast<bf16x4*>(dst + (p.N >> 1)) = lo;
+          } else {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((v[e] + bv[e]) * gelu_fast_f(g[e] + bg[e]));
+            *reinterpret_cast<bf16x4*>(dst) = o;
+          }
         } else {
           f32x4 o;
 #pragma unroll
@@ -486,6 +529,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(v[e] * gm[e]);
             *reinterpret_cast<bf16x4*>(out2 + o_out2 + n) = o;
+            if (p.out2_split) {      // bf16x3 mode: the lo plane of the (gamma-scaled) row, N columns further
+              bf16x4 lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) lo[e] = (bf16_t)(v[e] * gm[e] - (float)o[e]);
+              *reinterpret_cast<bf16x4*>(out2 + o_out2 + p.N + n) = lo;
+            }
             if (p.ssq) {
               const float ss = octet_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
               if ((lane & 7) == 0) p.ssq[(int64_t)m * p.ssq_ld + (n >> 5)] = ss;
