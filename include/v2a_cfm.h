@@ -208,6 +208,8 @@ typedef struct v2a_dwconv_norm {
   int64_t norm_step_stride, norm_batch_stride;
   float* norm_ssq;
   int64_t ld_norm_ssq;
+  int32_t split;          /* non-zero: out_bf16 rows in the V2A_BF16_SPLIT layout [hi d | lo d] (ld_out_bf16 >= 2 * d): bf16x3 mode */
+  int32_t reserved;
 } v2a_dwconv_norm;
 int v2a_dwconv_silu_residual_norm(const float* x, float* out, const float* wt, const float* bias,
                                   int32_t B, int32_t N, int32_t d, int32_t ksize,
@@ -245,6 +247,9 @@ typedef struct v2a_attn_args {
   float scale, softclamp;
   int32_t dtype;         /* V2A_F32 / V2A_BF16: dtype of q,k,v,gate,out and of the arithmetic; V2A_BF16_SPLIT: fp32 tensors,
                           * products as three bf16 MFMA passes over hi | lo operand planes (the bf16x3 mode) */
+  int32_t out_split;     /* dtype V2A_BF16_SPLIT only, non-zero: out is a bf16 buffer in the V2A_BF16_SPLIT layout -- row =
+                          * [hi of the H*64 outputs | lo of them], out_row_stride / out_batch_stride in bf16 elements -- i.e. the
+                          * A operand of the out-projection's split GEMM, written directly */
 } v2a_attn_args;
 
 int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);

@@ -729,10 +729,14 @@ def test_split_bf16_planes_and_three_segment_gemm(L):
     hi, lo = sp[:, :K].float().cpu(), sp[:, K:].float().cpu()
     assert torch.equal(hi, a.bfloat16().float()) and torch.equal(lo, (a - a.bfloat16().float()).bfloat16().float())
     assert float((hi + lo - a).abs().max()) < 2e-5 * float(a.abs().max())
-    W3 = pack_weight(w, DEV, torch.bfloat16, split=True)
-    assert len(W3) == 1 and W3[0].shape == (N, 3 * K)
+    W2 = pack_weight(w, DEV, torch.bfloat16, split=True)                    # [W_hi | W_lo]: the operand of the native split GEMM
+    assert W2.shape == (N, 2 * K) and torch.equal(W2[:, :K].cpu(), w.bfloat16())
+    W3 = torch.cat([W2[:, :K], W2[:, K:], W2[:, :K]], 1).contiguous()        # [W_hi | W_lo | W_hi] against [A_hi | A_hi | A_lo]
     out = torch.empty(M, N, device=DEV)
-    L.gemm([(sp, 2 * K, K), (sp, 2 * K, K), (sp[:, K:], 2 * K, K)], W3[0], out, M=M, N=N, compute=L.BF16)
+    L.gemm([(sp, 2 * K, K), (sp, 2 * K, K), (sp[:, K:], 2 * K, K)], W3, out, M=M, N=N, compute=L.BF16)
+    nat = torch.empty(M, N, device=DEV)
+    L.gemm([(sp, 2 * K, K)], W2, nat, M=M, N=N, compute=L.BF16, a_split=True)                       # same three products per K step, one launch
+    assert float((nat - out).abs().max()) < 2e-5
     ref = a.double() @ w.double().t()
     err3 = float((out.cpu().double() - ref).abs().max())
     out1 = torch.empty(M, N, device=DEV)

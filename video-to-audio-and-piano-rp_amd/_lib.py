@@ -52,7 +52,8 @@ class GemmArgs(C.Structure):
 class DwconvNorm(C.Structure):
     """Mirror of `v2a_dwconv_norm`: the RMSNorm after the depthwise convolution, folded into it."""
     _fields_ = [("out_bf16", C.c_void_p), ("ld_out_bf16", C.c_int64), ("norm_gamma", C.c_void_p), ("step", C.c_void_p),
-                ("norm_step_stride", C.c_int64), ("norm_batch_stride", C.c_int64), ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64)]
+                ("norm_step_stride", C.c_int64), ("norm_batch_stride", C.c_int64), ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64),
+                ("split", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Tuning(C.Structure):
@@ -71,7 +72,7 @@ class AttnArgs(C.Structure):
         ("gate_batch_stride", C.c_int64), ("out_batch_stride", C.c_int64),
         ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32),
         ("kv_len", C.c_void_p), ("q_len", C.c_void_p),
-        ("scale", C.c_float), ("softclamp", C.c_float), ("dtype", C.c_int32),
+        ("scale", C.c_float), ("softclamp", C.c_float), ("dtype", C.c_int32), ("out_split", C.c_int32),
     ]
 
 
@@ -366,6 +367,9 @@ def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm=None):
     n.norm_gamma, n.step = norm["gamma"].data_ptr(), _p(norm.get("step"))
     n.norm_step_stride, n.norm_batch_stride = norm.get("step_stride", 0), norm.get("batch_stride", 0)
     n.norm_ssq, n.ld_norm_ssq = norm["ssq"].data_ptr(), norm["ssq"].stride(-2)
+    n.split = 1 if norm.get("split") else 0
+    if n.split:
+        n.ld_out_bf16 = norm.get("ld_out_bf16", 2 * d)
     _launch("dwconv+norm", 2.0 * B * N * d * ksize, B * N * d * 10,
             lambda: lib().v2a_dwconv_silu_residual_norm(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
                                                         B, N, d, ksize, _p(lens), C.byref(n), stream_ptr()))
@@ -377,7 +381,7 @@ def rope(qk, *, rows, row_stride, nheads, rows_per_batch, pos_offset, table, lay
                                            pos_offset, table.data_ptr(), layout, stream_ptr()))
 
 
-def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype):
+def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype, out_split=False):
     """q,k,v,gate,out: integer device addresses (views into fused buffers)."""
     a = AttnArgs()
     a.q, a.k, a.v, a.gate, a.out = q, k, v, gate, out
@@ -386,6 +390,7 @@ def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=N
     a.B, a.H, a.Nq, a.Nk = B, H, Nq, Nk
     a.kv_len, a.q_len = _p(kv_len), _p(q_len)
     a.scale, a.softclamp, a.dtype = scale, softclamp, dtype
+    a.out_split = 1 if out_split else 0
     esz = 2 if dtype == BF16 else 4
     _launch("attention<%s>" % {BF16: "bf16", F32: "f32", BF16_SPLIT: "bf16x3"}[dtype], 4.0 * B * H * Nq * Nk * 64,
             B * H * 64 * (2 * Nq + 2 * Nk) * esz, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))

@@ -24,6 +24,7 @@ struct AttnParams {
   const int32_t* kv_len;
   const int32_t* q_len;
   float scale, clamp;
+  int32_t out_split;     // split kernel only: out is a bf16 buffer that receives hi | lo planes (lo plane H * 64 columns after hi)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -624,6 +625,24 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
   float gt = 1.f;
   if (p.gate) gt = sigmoid_f(reinterpret_cast<const float*>(p.gate)[b * p.gbs + (int64_t)query * p.grs + h]);
   const float f = (query < qn && l > 0.f) ? gt / l : 0.f;
+  if (p.out_split) {
+    // the operand of the out-projection's split GEMM directly: hi | lo planes of the gated fp32 result, no v2a_split_bf16 pass
+    bf16_t* ob = reinterpret_cast<bf16_t*>(p.out) + b * p.obs + (int64_t)query * p.ors + h * 64 + 4 * g;
+    const int lo_off = p.H * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const f32x4 v = o[dt] * f;
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16_t)v[e];
+        lo[e] = (bf16_t)(v[e] - (float)hi[e]);
+      }
+      *reinterpret_cast<bf16x4*>(ob + 16 * dt) = hi;
+      *reinterpret_cast<bf16x4*>(ob + lo_off + 16 * dt) = lo;
+    }
+    return;
+  }
   float* op = reinterpret_cast<float*>(p.out) + b * p.obs + (int64_t)query * p.ors + h * 64 + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(op + 16 * dt) = o[dt] * f;
@@ -892,6 +911,8 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
   p.kv_len = a->kv_len; p.q_len = a->q_len;
   p.scale = a->scale; p.clamp = a->softclamp;
+  p.out_split = a->out_split ? 1 : 0;
+  V2A_REQUIRE(!a->out_split || a->dtype == V2A_BF16_SPLIT, "v2a_attention: out_split goes with dtype V2A_BF16_SPLIT");
   hipStream_t s = (hipStream_t)stream;
   int rc = V2A_OK;
   dim3 grid((a->Nq + 63) / 64, a->H, a->B), block(64);
@@ -902,6 +923,8 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
                          a->k_batch_stride % 4 == 0 && a->v_batch_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
     const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
     const int cl = attn_clamp_mode(a->softclamp, a->Nk);
+    V2A_REQUIRE(aligned || !a->out_split, "v2a_attention: out_split needs 16-byte aligned head slices");
+    if (a->out_split) V2A_REQUIRE(((uintptr_t)a->out & 7) == 0 && a->out_row_stride >= 2 * (int64_t)a->H * 64, "v2a_attention: split output rows hold 2 * H * 64 bf16");
     if (!aligned) {
       hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
     } else if (a->Nk > 128) {

@@ -227,6 +227,12 @@ __global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const floa
 #pragma unroll
             for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)(o[j] * gm[j]);
             *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(nrm.out_bf16) + row * nrm.ld_out_bf16 + 4 * cc) = ob;
+            if (nrm.split) {      // bf16x3 mode: the lo plane of the gamma-scaled row, d columns further
+              bf16x4 ol;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ol[j] = (bf16_t)(o[j] * gm[j] - (float)ob[j]);
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(nrm.out_bf16) + row * nrm.ld_out_bf16 + d + 4 * cc) = ol;
+            }
             const float ss = octet_sum(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
             if ((lane & 7) == 0) nrm.norm_ssq[row * nrm.ld_norm_ssq + (cc >> 3)] = ss;
           }
@@ -534,7 +540,7 @@ static int dwconv_launch(const float* x, float* out, const float* wt, const floa
   if (norm)
     V2A_REQUIRE(norm->out_bf16 && norm->norm_gamma && norm->norm_ssq && d % 32 == 0 && norm->ld_out_bf16 % 4 == 0 && norm->ld_out_bf16 >= d &&
                     ((uintptr_t)norm->out_bf16 & 7) == 0 && ((uintptr_t)norm->norm_gamma & 15) == 0 && norm->norm_step_stride % 4 == 0 &&
-                    norm->norm_batch_stride % 4 == 0 && norm->ld_norm_ssq >= d / 32,
+                    norm->norm_batch_stride % 4 == 0 && norm->ld_norm_ssq >= d / 32 && (!norm->split || norm->ld_out_bf16 >= 2 * (int64_t)d),
                 "v2a_dwconv: the folded norm needs out_bf16, norm_gamma, norm_ssq, d %% 32 == 0 (d=%d) and aligned rows", d);
   const int TN = norm ? 4 : v2a_detail::g_dwconv_rows_per_wave;
   const int cb = (d / 4 + 63) / 64;                      // 256-channel blocks

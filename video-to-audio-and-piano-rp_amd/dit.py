@@ -66,22 +66,16 @@ def _ru(x, m):
 
 
 def pack_weight(w, dev, cd, split=False, ksegs=None):
-    """nn.Linear weight [N][K] -> device operand.  Plain modes: one tensor in the compute dtype.  split (bf16x3 mode): one
-    tensor PER K segment (ksegs: the K extents of the concatenated inputs, default one segment), each [N][3*Ks] bf16 =
-    [W_hi | W_lo | W_hi] with W_hi = bf16(W), W_lo = bf16(W - W_hi): against the operand [A_hi | A_hi | A_lo] a three-segment
-    bf16 GEMM then sums hi*hi + hi*lo + lo*hi in fp32 (include/v2a_cfm.h, V2A_BF16_SPLIT)."""
+    """nn.Linear weight [N][K] -> device operand.  Plain modes: one tensor in the compute dtype.  split (bf16x3 mode): [N][2K] bf16 =
+    [W_hi | W_lo] with W_hi = bf16(W), W_lo = bf16(W - W_hi): against A rows [A_hi | A_lo] the split GEMM (v2a_gemm, a_dtype
+    V2A_BF16_SPLIT) sums A_lo W_hi + A_hi W_lo + A_hi W_hi in fp32 per K step, over all logical K segments in one launch (`ksegs` is
+    kept for the callers' documentation of the concatenated inputs; the layout does not depend on it)."""
     w = w.float()
     if not split:
         return w.to(dev, cd).contiguous()
-    out, k0 = [], 0
-    for k in (ksegs or [w.shape[1]]):
-        ws = w[:, k0:k0 + k]
-        hi = ws.bfloat16()
-        lo = (ws - hi.float()).bfloat16()
-        out.append(torch.cat([hi, lo, hi], 1).contiguous().to(dev))
-        k0 += k
-    assert k0 == w.shape[1]
-    return out
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    return torch.cat([hi, lo], 1).contiguous().to(dev)
 
 
 class _Attn:
@@ -256,6 +250,7 @@ class DiTEngine:
         self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
                            ("f", "ff1"): 6, ("f", "qkv"): 6}
         self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
+        self.split_tiles = {}           # bf16x3 mode: (stream, op) -> split-operand tile shape 1..4 of v2a_gemm (default: by shape)
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
@@ -318,9 +313,6 @@ class DiTEngine:
             p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=self.ad)
             p[f"ao_{s}"] = e(rows, w2 * attn.inner, dt=cd)
             p[f"ffh_{s}"] = e(rows, w2 * ff.inner, dt=cd)
-            if self.split:                    # fp32 results that are split into operand planes afterwards
-                p[f"ao32_{s}"] = e(rows, attn.inner)
-                p[f"ffh32_{s}"] = e(rows, ff.inner)
         # bf16 shadows of the fp32 residual streams (written by the producing GEMM epilogues): the
         # operands of the cross-condition / skip GEMMs, so those run on the LDS-DMA bf16 kernel too
         p["shadow"] = {}
@@ -378,7 +370,7 @@ class DiTEngine:
         the tuning knobs on this object and the per-call state prepare() leaves in the plan."""
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
-                tuple(sorted(self.big_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.cross_on_main,
+                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.cross_on_main,
                 self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
@@ -392,25 +384,17 @@ class DiTEngine:
         return buf if s is None else s
 
     def _mm(self, segs, W, out, **kw):
-        """GEMM on logical K segments [(operand buffer, lda, k)].  Plain modes: one v2a_gemm.  bf16x3: every logical segment
-        is its own launch on the three physical segments [A_hi | A_hi | A_lo] against [W_hi | W_lo | W_hi] (pack_weight);
-        launches after the first accumulate in place (RESID with resid = out), a requested bf16 shadow of the result is
-        produced by v2a_split_bf16 afterwards."""
+        """GEMM on logical K segments [(operand buffer, lda, k)].  Plain modes: one v2a_gemm.  bf16x3: the operand buffers hold
+        hi | lo planes (rows of 2k bf16) and W is [W_hi | W_lo]: one v2a_gemm with split operands (three MFMA products per fp32
+        product inside the kernel); a requested bf16 shadow of the result is written as hi | lo planes by the same epilogue."""
+        if kw.get("out_bf16") is not None and "ld_out_bf16" not in kw:
+            kw["ld_out_bf16"] = kw["out_bf16"].stride(-2)        # a shadow may be half of a wider operand buffer
         if not self.split:
-            if kw.get("out_bf16") is not None and "ld_out_bf16" not in kw:
-                kw["ld_out_bf16"] = kw["out_bf16"].stride(-2)        # a shadow may be half of a wider operand buffer
             return L.gemm(segs, W, out, compute=self.cdc, **kw)
-        shadow = kw.pop("out_bf16", None)
-        for si, (buf, _, k) in enumerate(segs):
-            b2 = buf.reshape(-1, 2 * k)
-            kwi = dict(kw)
-            if si > 0:
-                kwi.update(bias=None, resid=out, ldr=kw.get("ldo"))
-                if kwi.get("epilogue", L.EPI_STORE) == L.EPI_STORE:
-                    kwi["epilogue"] = L.EPI_RESID
-            L.gemm([(b2, 2 * k, k), (b2, 2 * k, k), (b2[:, k:], 2 * k, k)], W[si], out, compute=L.BF16, **kwi)
-        if shadow is not None:
-            L.split_bf16(out, shadow, rows=kw["M"], d=kw["N"], ldx=kw.get("ldo"))
+        segs = [(buf, buf.stride(-2), k) for buf, _, k in segs]
+        if kw.get("out_bf16") is not None:
+            kw["out_bf16_split"] = True
+        return L.gemm(segs, W, out, compute=L.BF16, a_split=True, **kw)
 
     def _norm_plain(self, x, hn, rows, d, g):
         L.rmsnorm(x, hn, rows=rows, d=d, gamma=g, split=self.split)
@@ -429,7 +413,7 @@ class DiTEngine:
 
     def _fold(self):
         c = self.cfg
-        return (self.fold_norm and not self.split and self.cd == torch.bfloat16
+        return (self.fold_norm and self.cd == torch.bfloat16
                 and all(d % 32 == 0 and d <= 1280 for d in (c.dim, c.dim_text, c.dim_frames)))
 
     def _fold_gemm(self):
@@ -480,25 +464,21 @@ class DiTEngine:
         es = qkv.element_size()
         base = qkv.data_ptr()
         lens = p["seq_len"] if p["ragged"] else None
-        aout = p[f"ao32_{s}"] if self.split else ao
-        L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, aout.data_ptr(),
-                    strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, A.inner,
-                             N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.inner),
+        aw = ao.stride(-2)                      # inner, or 2 * inner in bf16x3 mode: the kernel writes hi | lo planes itself
+        L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
+                    strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, aw,
+                             N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * aw),
                     B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens,
                     q_len=lens if self.zero_masked_queries else None,
-                    scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc)
-        if self.split:
-            L.split_bf16(aout, ao, rows=rows, d=A.inner)
+                    scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
         self._mm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, resid=x, ldo=d, ldr=d, **out_kw)
 
     def _ff(self, Fw: _FF, x, s, nseq, d, out_kw, in_kw={}):
         p = self.plan
         rows = nseq * p["N"]
         hn, ffh = p[f"hn_{s}"], p[f"ffh_{s}"]
-        h1 = p[f"ffh32_{s}"] if self.split else ffh
-        self._mm([(hn, d, d)], Fw.w1, h1, M=rows, N=2 * Fw.inner, epilogue=L.EPI_GEGLU, bias=Fw.b1, ldo=Fw.inner, **in_kw)
-        if self.split:
-            L.split_bf16(h1, ffh, rows=rows, d=Fw.inner)
+        self._mm([(hn, d, d)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, epilogue=L.EPI_GEGLU, bias=Fw.b1, ldo=ffh.stride(-2),
+                 **(dict(out_split=True) if self.split else {}), **in_kw)
         out_kw = dict(out_kw)
         shadow = out_kw.pop("out_bf16", self._sh(x))         # the audio stream redirects it into a wide operand buffer (forward)
         self._mm([(ffh, Fw.inner, Fw.inner)], Fw.w2, x, M=rows, N=d, bias=Fw.b2, resid=x, ldo=d, ldr=d, out_bf16=shadow, **out_kw)
@@ -508,6 +488,8 @@ class DiTEngine:
         two clips: M <= 3128 rows); with more rows every kernel fills all CUs and the library's stand-alone choice is faster
         (8 clips: text feed-forward 325 us on the 256x256 kernel against 556 us on forced 128x256 tiles).  `side_tiles` maps
         (stream, op) to a tile configuration of v2a_tuning.gemm_force_tile; missing entries take `side_tile`."""
+        if self.split:                      # split-operand GEMMs have their own four tile shapes (v2a_gemm): 0 = by shape
+            return self.split_tiles.get((stream, op), 0)
         if self.side_tile < 0:
             return 0
         if self.plan["rows"] > 3200:
@@ -517,6 +499,9 @@ class DiTEngine:
         return self.side_tiles.get((stream, op), self.side_tile) + 1
 
     def _main_hint(self, op=None):
+        if self.split:
+            t = self.split_tiles.get(("a", op), 0)
+            return dict(tile_hint=t) if t else {}
         if self.plan["rows"] > 3200:
             t = self.big_tiles.get(("a", op), -1)
             return dict(tile_hint=t + 1) if t >= 0 else {}
@@ -542,12 +527,12 @@ class DiTEngine:
         if 0 in parts:
             if fold:
                 L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens,
-                         norm=dict(out_bf16=hn, gamma=ly[f"{s}_g1"], ssq=ssq))
+                         norm=dict(out_bf16=hn, ld_out_bf16=hn.stride(-2), gamma=ly[f"{s}_g1"], ssq=ssq, split=self.split))
             else:
                 L.dwconv(src, dst, cv.wt, cv.b, B=nseq, N=N, d=d, ksize=cv.k, lens=lens)
                 self._norm_plain(dst, hn, rows, d, ly[f"{s}_g1"])
         if 1 in parts:
-            prod = dict(out_bf16=hn, ld_out_bf16=d, norm_gamma=ly[f"{s}_g2"], norm_ssq=ssq) if fold2 else {}
+            prod = dict(out_bf16=hn, ld_out_bf16=hn.stride(-2), norm_gamma=ly[f"{s}_g2"], norm_ssq=ssq) if fold2 else {}
             self._self_attn(ly[f"{s}_attn"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **ho, **prod), cons)
         if 2 in parts:
             if not fold2:
@@ -653,11 +638,11 @@ class DiTEngine:
         L.linear_small(y, W.pin_wt, W.pin_b, p["padd"] if p["has_cond"] else W.pos_emb, p["xA"], M=B * T, K=c.num_channels, T=T,
                        out_batch_stride=N * D, row_off=c.num_registers, d=D, dup=(B if Bt > B else 0),
                        regs=W.regs, out_bf16=None if self.split else self._sh(p["xA"]))
+        if self.split:              # operand planes of x0 (both halves); the conditional half is rewritten by the GEMM below
+            L.split_bf16(p["xA"], self._sh(p["xA"]), rows=Bt * N, d=D)
         if p["has_cond"]:           # conditional half: x += cond_proj_in.weight @ step_cond (the bias sits in the position table)
             self._mm([(p["condbuf"], W.cond_k, W.cond_k)], W.cond_w, p["xA"], M=B * N, N=D, epilogue=L.EPI_RESID, resid=p["xA"],
-                     ldo=D, ldr=D, out_bf16=None if self.split else self._sh(p["xA"]))
-        if self.split:
-            L.split_bf16(p["xA"], self._sh(p["xA"]), rows=Bt * N, d=D)
+                     ldo=D, ldr=D, out_bf16=self._sh(p["xA"]))
 
     def forward(self, n_ctx_seqs: int | None = None):
         """Transformer.forward over the plan's Bt sequences starting from xA; result in plan['pred'].
@@ -780,8 +765,8 @@ class DiTEngine:
             if fold:
                 n0 = self._nprod_ada(i, 0)
                 L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens,
-                         norm=dict(out_bf16=p["hn_a"], gamma=n0["norm_gamma"], ssq=p["ssq_a"], step=n0.get("step"),
-                                   step_stride=n0.get("norm_step_stride", 0), batch_stride=n0.get("norm_batch_stride", 0)))
+                         norm=dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), gamma=n0["norm_gamma"], ssq=p["ssq_a"], step=n0.get("step"),
+                                   step_stride=n0.get("norm_step_stride", 0), batch_stride=n0.get("norm_batch_stride", 0), split=self.split))
             else:
                 L.dwconv(src, dst, cv.wt, cv.b, B=Bt, N=N, d=D, ksize=cv.k, lens=lens)
                 self._norm_ada(x, p["hn_a"], rows, D, i, 0)
@@ -790,7 +775,7 @@ class DiTEngine:
                 # feed-forward's (slot 2) for the rest
                 n1 = self._nprod_ada(i, 1, switch_row=r2 if r2 < rows else 0) if nctx > 0 else self._nprod_ada(i, 2)
                 n1 = {k: v for k, v in n1.items() if k not in ("step", "rows_per_batch")}       # the gate already passes them
-                prod1 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n1)
+                prod1 = dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), **n1)
             self._self_attn(ly["a_attn"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), **mh("out"), **prod1), dict(**cons, **mh("qkv")))
             if not last and self.interleave_capture:
                 for part in (0, 1):
@@ -818,19 +803,17 @@ class DiTEngine:
                 es = q2.element_size()
                 kb = p["ctx_kv"].data_ptr() + i * inner * es
                 vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
-                aout = p["ao32_a"] if self.split else p["ao_a"]
-                L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, aout.data_ptr(),
-                            strides=(A2.n_pad, nkv, nkv, A2.n_pad, inner,
-                                     N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * inner),
+                aw = p["ao_a"].stride(-2)
+                L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, p["ao_a"].data_ptr(),
+                            strides=(A2.n_pad, nkv, nkv, A2.n_pad, aw,
+                                     N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * aw),
                             B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
                             q_len=lens if self.zero_masked_queries else None,
-                            scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc)
-                if self.split:
-                    L.split_bf16(aout, p["ao_a"], rows=r2, d=inner)
+                            scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
                 prod2 = {}
                 if fold2:
                     n2 = {k: v for k, v in self._nprod_ada(i, 2).items() if k not in ("step", "rows_per_batch")}
-                    prod2 = dict(out_bf16=p["hn_a"], ld_out_bf16=D, **n2)
+                    prod2 = dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), **n2)
                 self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
                          epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh("out2"), **prod2)
             if not fold2:
