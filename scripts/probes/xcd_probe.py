@@ -31,10 +31,20 @@ class Member:
         self.epi = f[3] if len(f) > 3 else "resid"
         g = torch.Generator().manual_seed(idx)
         M, N, K = self.M, self.N, self.K
-        self.a = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
-        self.w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, torch.bfloat16)
+        self.split = self.epi.startswith("s3")          # split (hi | lo plane) operands: K is the LOGICAL K, three products per step
+        if self.split:
+            self.epi = self.epi[2:] or "resid"
+        kk = 2 * K if self.split else K
+        self.a = (torch.randn(M, kk, generator=g) * 0.5).to(DEV, torch.bfloat16)
+        self.w = (torch.randn(N, kk, generator=g) * 0.05).to(DEV, torch.bfloat16)
         self.ctr = torch.zeros(16, dtype=torch.int32, device=DEV)
-        if self.epi == "geglu":
+        if self.epi == "store" and self.split:
+            self.out = torch.empty(M, N, device=DEV)
+            self.kw = dict()
+        elif self.epi == "geglu" and self.split:
+            self.out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            self.kw = dict(epilogue=_lib.EPI_GEGLU, ldo=N, out_split=True)
+        elif self.epi == "geglu":
             self.out = torch.empty(M, N // 2, device=DEV, dtype=torch.bfloat16)
             self.kw = dict(epilogue=_lib.EPI_GEGLU, ldo=N // 2)
         elif self.epi == "store":
@@ -44,13 +54,19 @@ class Member:
             self.res = torch.randn(M, N, generator=g).to(DEV)
             self.out = torch.empty(M, N, device=DEV)
             self.kw = dict(epilogue=_lib.EPI_RESID, resid=self.res)
-        self.flops = 2.0 * M * N * K
+        self.flops = (6.0 if self.split else 2.0) * M * N * K
 
     def run(self):
+        if self.split:
+            _lib.gemm([(self.a, 2 * self.K, self.K)], self.w, self.out, M=self.M, N=self.N, compute=_lib.BF16, tile_hint=self.tile + 1,
+                      a_split=True, **self.kw)
+            return
         _lib.gemm([(self.a, self.K, self.K)], self.w, self.out, M=self.M, N=self.N, compute=_lib.BF16, tile_hint=self.tile + 1,
                   xcd_mask=self.mask, tile_counters=self.ctr, **self.kw)
 
     def check(self):
+        if self.split:
+            return True
         self.out.zero_()
         self.run()
         torch.cuda.synchronize()

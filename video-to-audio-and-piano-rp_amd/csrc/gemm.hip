@@ -714,11 +714,28 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   }
   if (split_in) {
     V2A_REQUIRE(p.vec_epi && !a->a_row_offset && !a->out_row_offset, "v2a_gemm: split operands need dense rows and 16-byte aligned epilogue operands");
-    V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 4, "v2a_gemm: tile_hint %d with split operands (0 = by shape, 1..4)", a->tile_hint);
+    V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 5, "v2a_gemm: tile_hint %d with split operands (0 = by shape, 1..5)", a->tile_hint);
     auto nt = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
     // split-operand tile shapes (hi + lo planes double a stage): 1 = 64x64 (96 KB), 2 = 128x64 (144 KB), 3 = 128x128 with 8 waves and a
     // 2-deep ring (128 KB), 4 = 64x128 with 8 waves (144 KB)
     int cfg = a->tile_hint;
+    // wide outputs with enough 256x256 tiles: the phase-interleaved kernel on three K segments [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]
+    // (audio feed-forward at one clip: 76 us against 102 us on the best split ring tile; it re-reads A_hi and W_hi, but its K loop
+    // hides the operand stream behind the MFMAs).  One logical segment only; tile_hint 5 asks for it, 0 picks by shape.
+    const bool wide8 = a->nseg == 1 && tune.use_8phase && (cfg == 5 || (cfg == 0 && a->N >= 2048 && nt(256, 256) >= 150));
+    if (wide8) {
+      GemmParams q = p;
+      const int64_t k1 = a->ka[0];
+      q.nseg = 3;
+      q.a[0] = q.a[1] = a->a[0];
+      q.a[2] = reinterpret_cast<const bf16_t*>(a->a[0]) + k1;
+      q.lda[0] = q.lda[1] = q.lda[2] = a->lda[0];
+      q.kend[0] = (int32_t)k1; q.kend[1] = (int32_t)(2 * k1); q.kend[2] = (int32_t)(3 * k1);
+      q.K = (int32_t)(3 * k1);
+      q.w_adj2 = -4 * k1;        // bytes: segment 2 reads W_hi again
+      return v2a_detail::launch_gemm_8phase(q, a->epilogue, a->out_dtype == V2A_BF16_SPLIT ? V2A_BF16 : a->out_dtype, s);
+    }
+    V2A_REQUIRE(cfg != 5, "v2a_gemm: tile_hint 5 (8-phase) with split operands needs one segment");
     if (cfg == 0) {
       if (a->epilogue == V2A_EPI_GEGLU || a->N >= 2048) cfg = nt(128, 128) >= 200 ? 3 : 4;
       else cfg = nt(64, 128) >= 160 ? 4 : 1;

@@ -93,8 +93,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
                                        (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
     }
   };
+  const int64_t w_adj2 = p.w_adj2;
   auto stage_b = [&](int s, int kt, int buf) {
-    const char* wb = wbase + (int64_t)kt * 128;
+    const char* wb = wbase + (int64_t)kt * 128 + (kt * 64 >= kend1 ? w_adj2 : 0);
     char* dst = smem_raw + buf * BUF + (2 + s) * HALF;
 #pragma unroll
     for (int i = 0; i < 2; ++i)

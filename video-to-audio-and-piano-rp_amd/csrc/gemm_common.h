@@ -61,6 +61,10 @@ struct GemmParams {
   // split (hi | lo plane) outputs of the bf16x3 mode: out2 = the shadow (lo plane N columns after hi), out = the GEGLU hidden
   // (lo plane N / 2 columns after hi)
   int32_t out2_split, out_split;
+  // 8-phase kernel: byte adjustment of the W tile base for K tiles of the THIRD segment.  Split operands on that kernel run as
+  // three K segments [A_hi | A_hi | A_lo] against the weight row [W_hi | W_lo]: segments 0 and 1 walk the row as it lies, segment 2
+  // needs W_hi again (-2 * K_logical elements)
+  int64_t w_adj2;
   int32_t dbg;              // probe builds only (-DV2A_GEMM_PROBE, scripts/probes/kloop_probe.py): K-loop parts switched off by bit
 };
 
