@@ -15,16 +15,15 @@ while read -r spec; do
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo TIMEOUT; exit 99; fi
 done <<'LIST'
 _
---main-tile 12
---side-tiles t.cross=12,t.out=12,t.ff2=12
---side-tiles t.cross=15,t.out=15,t.ff2=15
---side-tiles t.cross=3,t.out=3,t.ff2=3
---main-tile 12 --side-tiles t.cross=12,t.out=12,t.ff2=12
+--side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
 --main-tile 12 --side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
---side-tiles f.cross=12,f.out=12,f.ff2=12
---side-tiles f.cross=3,f.out=3,f.ff2=3
---side-tiles a.qkv=12,t.qkv=12
---side-tiles a.qkv=3
+--side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12,a.qkv=3
+--side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12,t.qkv=12
+--side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=3,f.out=3,f.ff2=3
+--side-tiles t.cross=15,t.out=15,t.ff2=15,f.cross=3,f.out=3,f.ff2=3
+--main-tile 15 --side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
+--main-tile 14 --side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
+--side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12,f.qkv=3,f.ff1=0
 _
 LIST
 cat gpurun_out/tile_sweep.txt

@@ -11,7 +11,7 @@
 //     the softmax row reductions done by wavefront shuffles.
 #include "v2a_common.h"
 
-namespace v2a_detail { extern int g_attn_one_group_from; }
+namespace v2a_detail { extern int g_attn_one_group_from; extern int g_probe_dbg; }
 
 namespace {
 
@@ -25,6 +25,7 @@ struct AttnParams {
   const int32_t* q_len;
   float scale, clamp;
   int32_t out_split;     // split kernel only: out is a bf16 buffer that receives hi | lo planes (lo plane H * 64 columns after hi)
+  int32_t dbg;           // probe builds only
 };
 
 // ------------------------------------------------------------------------------------------
@@ -496,8 +497,15 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
         const int off = row * 64 + (((kk * 4 + g) ^ (row & 7)) << 3);
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(ksh + off);
         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(ksl + off);
+#ifdef V2A_GEMM_PROBE     // error attribution: hi planes only = the bf16 kernel's products
+        if (!(p.dbg & 32)) {
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[kk], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[kk], s[t], 0, 0, 0);
+        }
+#else
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[kk], s[t], 0, 0, 0);
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[kk], s[t], 0, 0, 0);
+#endif
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[kk], s[t], 0, 0, 0);
       }
     }
@@ -587,8 +595,15 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(AttnParams p)
             vfl[4 + j] = hi2[j];
           }
         }
+#ifdef V2A_GEMM_PROBE
+        if (!(p.dbg & 32)) {
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pfh[ks2], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, pfl[ks2], o[dt], 0, 0, 0);
+        }
+#else
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, pfh[ks2], o[dt], 0, 0, 0);
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, pfl[ks2], o[dt], 0, 0, 0);
+#endif
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfh, pfh[ks2], o[dt], 0, 0, 0);
       }
     }
@@ -912,6 +927,7 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   p.kv_len = a->kv_len; p.q_len = a->q_len;
   p.scale = a->scale; p.clamp = a->softclamp;
   p.out_split = a->out_split ? 1 : 0;
+  p.dbg = v2a_detail::g_probe_dbg;
   V2A_REQUIRE(!a->out_split || a->dtype == V2A_BF16_SPLIT, "v2a_attention: out_split goes with dtype V2A_BF16_SPLIT");
   hipStream_t s = (hipStream_t)stream;
   int rc = V2A_OK;

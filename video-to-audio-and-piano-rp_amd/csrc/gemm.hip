@@ -410,8 +410,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+#ifdef V2A_GEMM_PROBE     // error attribution (tests/precision_attribution.py): bit 5 drops the two cross products = plain bf16 arithmetic
+            if (!(p.dbg & 32)) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfl[kk][j], acc[i][j], 0, 0, 0);
+            }
+#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bfl[kk][j], acc[i][j], 0, 0, 0);
+#endif
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
           }
     } else {
@@ -532,6 +539,7 @@ static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400, 1, 0};
 v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 int v2a_detail::g_attn_one_group_from = 1536;
+int v2a_detail::g_probe_dbg = 0;       // v2a_tuning.reserved[0]: read by probe builds only
 
 extern "C" int v2a_gemm_args_size(void) { return (int)sizeof(v2a_gemm_args); }
 
@@ -540,6 +548,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
     v2a_detail::g_gemm_tuning = kDefaultTuning;
     v2a_detail::g_dwconv_rows_per_wave = 4;
     v2a_detail::g_attn_one_group_from = 1536;
+    v2a_detail::g_probe_dbg = 0;
     return V2A_OK;
   }
   // every field is checked before any is assigned: a rejected call leaves the previous tuning whole
@@ -553,6 +562,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,
                                t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,
                                t->gemm_xcd_order_1x8 ? 0 : 1, t->reserved[0]};
+  v2a_detail::g_probe_dbg = t->reserved[0];
   return V2A_OK;
 }
 
@@ -733,6 +743,9 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
       q.kend[0] = (int32_t)k1; q.kend[1] = (int32_t)(2 * k1); q.kend[2] = (int32_t)(3 * k1);
       q.K = (int32_t)(3 * k1);
       q.w_adj2 = -4 * k1;        // bytes: segment 2 reads W_hi again
+#ifdef V2A_GEMM_PROBE
+      if (tune.dbg & 32) { q.nseg = 1; q.K = (int32_t)k1; }      // error attribution: hi x hi only
+#endif
       return v2a_detail::launch_gemm_8phase(q, a->epilogue, a->out_dtype == V2A_BF16_SPLIT ? V2A_BF16 : a->out_dtype, s);
     }
     V2A_REQUIRE(cfg != 5, "v2a_gemm: tile_hint 5 (8-phase) with split operands needs one segment");

@@ -247,9 +247,14 @@ class DiTEngine:
         # phase-interleaved kernel (+0.6 %), frames QKV too (49 tiles: +1.7 %).  Each entry A/B-ed alone and in combination on one box (bench.py --side-tiles).
         self.fuse_skip = True           # bf16 mode: cross-condition + skip projection of layers >= depth/2 as one GEMM (PackedWeights)
         self.big_tiles = {}             # the same kind of table for launches of more than two clips (default: library choice)
-        self.side_tiles = {("t", "cross"): 1, ("t", "out"): 1, ("t", "ff2"): 1, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
-                           ("f", "ff1"): 6, ("f", "qkv"): 6}
-        self.main_tile = -1             # A/B: tile configuration of the audio stream's narrow-output GEMMs (-1 = library choice)
+        # Round 3 (lean K loop, 8-wave variants of the small tiles): the narrow text / frames GEMMs on 128x128 tiles with EIGHT waves
+        # (tile 12: two waves per SIMD cover each other's DMA issue and LDS reads; 96 KB, so a 64-row audio workgroup still fits
+        # beside it) and the audio stream's narrow GEMMs on 128x64 tiles with eight waves (tile 14): 5690 -> 5817 mel-frames/s on one
+        # box (profiles/r03_tile_sweep.txt); 64x128 / 8 waves for the text stream is faster alone and 4.6 % slower in the sampler
+        # (144 KB of LDS: nothing else fits on the CU).
+        self.side_tiles = {("t", "cross"): 12, ("t", "out"): 12, ("t", "ff2"): 12, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
+                           ("f", "ff1"): 6, ("f", "qkv"): 6, ("f", "cross"): 12, ("f", "out"): 12, ("f", "ff2"): 12}
+        self.main_tile = 14             # tile configuration of the audio stream's narrow-output GEMMs at one clip (-1 = library choice)
         self.split_tiles = {}           # bf16x3 mode: (stream, op) -> split-operand tile shape 1..4 of v2a_gemm (default: by shape)
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
