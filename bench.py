@@ -13,16 +13,18 @@ shapes; they are resident in HBM before the timed region, which covers everythin
 of latents.  Ranks are clip-sharded (weak scaling, no per-step communication).
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries
-  roofline     : the dominant kernel (bf16 MFMA GEMM instantiation with the most time per evaluation), measured live with
-                 HIP events recorded BETWEEN the nodes of a single-stream hipGraph of one Euler evaluation (every kernel
-                 launched once, in its real cache state; interval = kernel + the launch boundary behind it), plus an
-                 `hbm` block for the memory-bound kernels at 1 and 8 clips per GPU;
+  roofline     : the dominant kernel class (the bf16 MFMA GEMM instantiation with the most time per evaluation) of the
+                 configuration the sampler RUNS -- three streams, the per-(stream, op) tile table -- measured live with HIP
+                 event pairs on the stream each kernel is launched on (`scope: production`); `standalone` holds the same class
+                 with every kernel alone on the chip (one stream, the library's tile choices), `traffic` the recorded PMC bytes
+                 per launch next to the algorithmic bytes, and `hbm` the memory-bound kernels at 1 and 8 clips per GPU;
   parity_mode  : throughput AND max |delta mel| over the whole 32-point grid against the committed oracle vector
                  (tests/golden/sample_full.npz) for the fp32 parity mode, the split-bf16 mode (bf16x3) and the bf16
                  headline mode;
   v2p, cascade : BASELINE configs[3] / [4] as supplementary measurements;
   cpu_baseline : the CPU restatement of the reference (oracle/, "port") timed on this box's host
-                 cores on a bounded sample of the same workload (steps=4: 3 CFG evaluations).
+                 cores on a bounded sample of the same workload (steps=4: 3 CFG evaluations; one warm-up run,
+                 median of three).
 With N > 1 the default is 8 clips per GPU (BASELINE configs[2]: 64 clips on 8 GPUs).
 """
 from __future__ import annotations
@@ -60,8 +62,9 @@ _T0 = time.perf_counter()
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PMC_FILES = ("r02_pmc1_summary.csv", "r02_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
-ROCPROF_STATS = "r02_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
+PMC_FILES = ("r03_pmc1_summary.csv", "r03_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
+ROCPROF_STATS = "r03_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
+ROCPROF_STATS_MULTI = "r03_kernel_stats_multistream.csv"         # ... of the production configuration (three streams)
 
 
 def main():
@@ -146,6 +149,7 @@ def main():
     model.engine().multi_stream = not args.single_stream
     if args.single_stream:
         model.engine().side_tile = -1
+        model.engine().main_tile = -1
     elif args.side_tile >= -1:
         model.engine().side_tile = args.side_tile
     if args.main_tile >= 0:
@@ -237,12 +241,12 @@ def main():
             if not args.no_roofline:
                 r8 = roofline_leg(model, L, args)
                 hbm["clips_8"] = r8.pop("hbm")
-                res["batched"]["roofline"] = {k: r8[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "launches_per_eval", "all_gemm_tflops",
+                res["batched"]["roofline"] = {k: r8[k] for k in ("kernel", "scope", "achieved", "frac", "avg_launch_us", "launches_per_eval", "all_gemm_tflops",
                                                                    "all_gemm_frac", "eval_kernel_ms", "kernels")}
             log("batched leg done")
         if not args.no_roofline:
             one_step()                                     # restore this run's plan (and its graph) after the batched leg
-            res["roofline"] = roofline_leg(model, L, args)
+            res["roofline"] = roofline_leg(model, L, args, production=not args.single_stream)
             hbm["clips_%d" % B] = res["roofline"].pop("hbm")
             res["roofline"]["hbm"] = hbm
             log("roofline leg done")
@@ -394,22 +398,26 @@ def batched_leg(model, cfg, cfm_steps, args, T, NC, dev):
     return {"clips_per_gpu": Bb, "mel_frames_per_s": round(Bb * T / el, 2), "ms_per_step": round(el * 1e3, 2), "clips_per_s": round(Bb / el, 3)}
 
 
-def _timed_evaluation(model, L, args, reps, shapes=False):
-    """Per-kernel time of ONE Euler evaluation of the model's current plan, kernels one at a time on one stream (the
-    production kernels, tile hints included), HIP events recorded on the stream the kernels are launched on."""
+def _timed_evaluation(model, L, args, reps, shapes=False, production=False):
+    """Per-kernel time of ONE Euler evaluation of the model's current plan, HIP events recorded on the stream each kernel is
+    launched on.  production=False: kernels one at a time on one stream with the library's stand-alone tile choices (isolated
+    launch durations).  production=True: the configuration sample() runs -- side streams and the per-(stream, op) tile table --
+    so every duration is that of the kernel BESIDE the other two streams' kernels."""
     from v2a_amd.dit import process_streams
     eng = model.engine()
     p = eng.plan
     y = p["y"]
-    side = (p.pop("st", None), p.pop("sf", None))     # no side streams: isolated launch durations
-    side_tile, eng.side_tile = eng.side_tile, -1      # ... of the library's stand-alone tile choices (as `--single-stream` under rocprofv3)
+    side = (None, None) if production else (p.pop("st", None), p.pop("sf", None))     # no side streams: isolated launch durations
+    side_tile, main_tile = eng.side_tile, eng.main_tile
+    if not production:
+        eng.side_tile, eng.main_tile = -1, -1         # ... of the library's stand-alone tile choices (as `--single-stream` under rocprofv3)
     keep = y.clone()
     p["step"].zero_()
     eng.euler_step(y, args.cfg_strength, False)       # warm
     torch.cuda.synchronize()
     how = "hip events between the nodes of a single-stream hipGraph (kernel + launch boundary)"
     prof = None
-    if args.graph_roofline:          # needs external event nodes in captured graphs: refused by torch on ROCm 7 ("External events
+    if args.graph_roofline and not production:          # needs external event nodes in captured graphs: refused by torch on ROCm 7 ("External events
         try:                         # are disallowed in rocm"), and hipEventRecordWithFlags inside a capture invalidates it
             prof = L.KernelProfiler(shapes=shapes, external=True)
             g = torch.cuda.CUDAGraph()
@@ -455,14 +463,31 @@ def _timed_evaluation(model, L, args, reps, shapes=False):
     p["step"].zero_()
     if side[0] is not None:
         p["st"], p["sf"] = side
-    eng.side_tile = side_tile
+    eng.side_tile, eng.main_tile = side_tile, main_tile
     return agg, how
 
 
-def roofline_leg(model, L, args):
+def _dominant(agg, reps, how, stats_file):
+    """The GEMM instantiation with the most time per evaluation in a timed evaluation, as a roofline record."""
+    gem = [(k, a) for k, a in agg.items() if k.startswith("gemm")]
+    dom_k, dom = max(gem, key=lambda kv: kv[1]["ms"])
+    peak = PEAK_BF16_TFLOPS if "bf16" in dom_k.split(",")[0] else PEAK_F32_TFLOPS
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    all_f = sum(a["flops"] for _, a in gem)
+    all_ms = sum(a["ms"] for _, a in gem)
+    return dom_k, dom, {"kernel": dom_k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "timing": how, "rocprof": rocprof_avg(dom_k, dom["flops"] / dom["launches"], peak, stats_file),
+                        "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2), "launches_per_eval": dom["launches"] // reps,
+                        "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
+                        "all_gemm_tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(all_f / (all_ms * 1e-3) / 1e12 / peak, 4)}
+
+
+def roofline_leg(model, L, args, production=False):
     """`achieved` = algorithmic FLOPs (2*M*N*K per launch) / measured time of the GEMM instantiation with the most time per
-    evaluation; `hbm` = algorithmic bytes / measured time of the memory-bound kernels against the 8 TB/s HBM peak.  The same
-    command under `rocprofv3 --kernel-trace --stats` gives the kernel-only durations committed in profiles/."""
+    evaluation; `hbm` = algorithmic bytes / measured time of the memory-bound kernels against the 8 TB/s HBM peak.  With
+    production=True the headline record is that of the configuration sample() runs (three streams, per-(stream, op) tile table:
+    every kernel timed beside the other streams' kernels) and `standalone` holds the same measurement with each kernel alone on
+    the chip; the same commands under `rocprofv3 --kernel-trace --stats` give the kernel-only durations committed in profiles/."""
     reps = 3
     agg, how = _timed_evaluation(model, L, args, reps)
     if args.shapes:       # per-shape GEMM table on stderr (tuning aid)
@@ -477,28 +502,39 @@ def roofline_leg(model, L, args):
             gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             hbm[k] = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
                       "MB_per_launch": round(a["bytes"] / a["launches"] / 1e6, 3), "achieved_GBs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
-    table, tot_ms = {}, sum(a["ms"] for a in agg.values())
-    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-        row = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
-               "share": round(a["ms"] / tot_ms, 4)}
-        if a["flops"] > 0 and k.startswith(("gemm", "attention")):
-            row["tflops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2)
-        else:
-            row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
-        table[k] = row
-    gem = [(k, a) for k, a in agg.items() if k.startswith("gemm")]
-    dom_k, dom = max(gem, key=lambda kv: kv[1]["ms"])
-    peak = PEAK_BF16_TFLOPS if "bf16" in dom_k.split(",")[0] else PEAK_F32_TFLOPS
-    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    all_f = sum(a["flops"] for _, a in gem)
-    all_ms = sum(a["ms"] for _, a in gem)
-    rp = rocprof_avg(dom_k, dom["flops"] / dom["launches"], peak)
-    return {"bound": "mfma", "kernel": dom_k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom_k), "timing": how, "rocprof": rp,
-            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2), "launches_per_eval": dom["launches"] // reps,
-            "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
-            "all_gemm_tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(all_f / (all_ms * 1e-3) / 1e12 / peak, 4),
-            "eval_kernel_ms": round(tot_ms / reps, 3), "kernels": table, "hbm": hbm}
+
+    def table_of(ag):
+        table, tot_ms = {}, sum(a["ms"] for a in ag.values())
+        for k, a in sorted(ag.items(), key=lambda kv: -kv[1]["ms"]):
+            row = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
+                   "share": round(a["ms"] / tot_ms, 4)}
+            if a["flops"] > 0 and k.startswith(("gemm", "attention")):
+                row["tflops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2)
+            else:
+                row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
+            table[k] = row
+        return table, tot_ms
+
+    dom_k, dom, alone = _dominant(agg, reps, how, ROCPROF_STATS)
+    table, tot_ms = table_of(agg)
+    alone.update({"scope": "standalone: one stream, every kernel alone on the chip, the library's tile choices",
+                  "eval_kernel_ms": round(tot_ms / reps, 3), "kernels": table})
+    alg = dom["bytes"] / dom["launches"]
+    out = {"bound": "mfma"}
+    if production:
+        pagg, phow = _timed_evaluation(model, L, args, reps, production=True)
+        pk, pdom, prod = _dominant(pagg, reps, phow, ROCPROF_STATS_MULTI)
+        ptable, ptot = table_of(pagg)
+        prod.update({"scope": "production: three streams and the per-(stream, op) tile table -- each kernel timed beside the other streams' kernels",
+                     "sum_of_kernel_ms_per_eval": round(ptot / reps, 3), "kernels": ptable})
+        out.update(prod)
+        out["standalone"] = alone
+        dom_k, alg = pk, pdom["bytes"] / pdom["launches"]
+    else:
+        out.update(alone)
+    out["traffic"] = pmc_traffic(dom_k, alg)
+    out["hbm"] = hbm
+    return out
 
 
 def parity_mode_leg(v2a_amd, cfg, args, dev):
@@ -591,23 +627,24 @@ def _kernel_rows(fn, kernel_key, name_col):
     return out
 
 
-def rocprof_avg(kernel_key, flops_per_launch, peak):
+def rocprof_avg(kernel_key, flops_per_launch, peak, stats_file=None):
     """The same kernel class in the committed `rocprofv3 --kernel-trace --stats` summary of `bench.py --single-stream`
     (profiles/): kernel-only duration, without the event packets the live figure includes."""
     try:
-        rows = _kernel_rows(ROCPROF_STATS, kernel_key, "Name")
+        stats_file = stats_file or ROCPROF_STATS
+        rows = _kernel_rows(stats_file, kernel_key, "Name")
         if not rows:
             return None
         best = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         us = float(best["AverageNs"]) / 1e3
         tf = flops_per_launch / (us * 1e-6) / 1e12
         return {"avg_us": round(us, 2), "calls": int(best["Calls"]), "achieved": round(tf, 2), "frac": round(tf / peak, 4),
-                "source": "profiles/%s (%s)" % (ROCPROF_STATS, best["Name"][:70])}
+                "source": "profiles/%s (%s)" % (stats_file, best["Name"][:70])}
     except Exception:
         return None
 
 
-def pmc_traffic(kernel_key):
+def pmc_traffic(kernel_key, algorithmic_bytes=None):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/ files named in PMC_FILES; FETCH_SIZE and WRITE_SIZE collected in separate passes, KB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC collection cannot run inside
@@ -621,8 +658,13 @@ def pmc_traffic(kernel_key):
             return None
         fetch = float(f["FETCH_SIZE"]) * 1024 * 2 / int(f["dispatches"])
         write = float(w["WRITE_SIZE"]) * 1024 / int(w["dispatches"])
-        return {"bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
-                "source": "profiles/%s + %s (rocprofv3 --pmc, separate passes; FETCH_SIZE x2)" % PMC_FILES}
+        out = {"bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
+               "source": "profiles/%s + %s (rocprofv3 --pmc, separate passes; FETCH_SIZE x2)" % PMC_FILES}
+        if algorithmic_bytes:
+            # operands once (A, W), the residual row read, the fp32 result and its bf16 shadow written: what one launch must move
+            out["algorithmic_bytes"] = round(algorithmic_bytes)
+            out["ratio"] = round((fetch + write) / algorithmic_bytes, 3)
+        return out
     except Exception:
         return None
 
@@ -639,17 +681,22 @@ def cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T):
     ocfg = O.DiTConfig()
     s = args.cpu_baseline_steps
     a = [t[:1].float().cpu() for t in (y0, text, roll, ctx)]
-    t0 = time.perf_counter()
-    ref = O.sample(P, ocfg, a[0], a[1], a[2], a[3], cm[:1], steps=s, cfg_strength=args.cfg_strength, remove_parallel_component=False)
-    cpu_s = time.perf_counter() - t0
+    runs = []
+    for i in range(4):                  # one warm-up, median of three
+        t0 = time.perf_counter()
+        ref = O.sample(P, ocfg, a[0], a[1], a[2], a[3], cm[:1], steps=s, cfg_strength=args.cfg_strength, remove_parallel_component=False)
+        if i > 0:
+            runs.append(time.perf_counter() - t0)
+    cpu_s = sorted(runs)[1]
     per_eval = cpu_s / (s - 1)
     full = per_eval * (32 - 1)
     # parity of the measured (bf16 or fp32) GPU path on the same bounded sample
     got = one_step(steps=s)[:1].float().cpu()
     err = (got - ref).abs()
     return {"cpu_baseline": {"value": round(T / full, 3), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                             "sample": "B=1, steps=%d (%d of 31 CFG evaluations = %d forwards, %.1f s CPU), extrapolated linearly in evaluations; "
-                                       "CPU restatement of the reference in plain torch fp32" % (s, s - 1, 2 * (s - 1), cpu_s),
+                             "sample": "B=1, steps=%d (%d of 31 CFG evaluations = %d forwards; one warm-up run, median of three: %.1f s CPU, runs %s), "
+                                       "extrapolated linearly in evaluations; CPU restatement of the reference in plain torch fp32"
+                                       % (s, s - 1, 2 * (s - 1), cpu_s, " / ".join("%.1f" % r for r in runs)),
                              "s_per_cfg_evaluation": round(per_eval, 3)},
             "parity": {"mode": args.dtype, "sample": "same steps=%d run, B=1 (the 32-point grid is in parity_mode)" % s, "max_abs_delta_mel": round(float(err.max()), 6),
                        "mean_abs_delta_mel": round(float(err.mean()), 7)}}

@@ -14,16 +14,12 @@ while read -r spec; do
   echo "[$spec] rc=$rc $v" | tee -a gpurun_out/tile_sweep.txt
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo TIMEOUT; exit 99; fi
 done <<'LIST'
+--no-row-split
 _
---side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
---main-tile 12 --side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
---side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12,a.qkv=3
---side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12,t.qkv=12
---side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=3,f.out=3,f.ff2=3
---side-tiles t.cross=15,t.out=15,t.ff2=15,f.cross=3,f.out=3,f.ff2=3
---main-tile 15 --side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
---main-tile 14 --side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12
---side-tiles t.cross=12,t.out=12,t.ff2=12,f.cross=12,f.out=12,f.ff2=12,f.qkv=3,f.ff1=0
+--no-row-split
+_
+--side-tiles a.qkv=12
+--no-row-split
 _
 LIST
 cat gpurun_out/tile_sweep.txt

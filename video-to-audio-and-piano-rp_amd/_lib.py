@@ -335,6 +335,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
     esz = 2 if compute == BF16 else 4
     nbytes = M * K * (4 if g.a_dtype == F32 else 2) + N * K * esz + M * (N // 2 if epilogue == EPI_GEGLU else N) * out.element_size()
+    nbytes += (M * N * 4 if resid is not None else 0) + (M * N * 2 if out_bf16 is not None else 0)      # residual rows read, bf16 shadow written
     if g.tile_hint:
         key = key[:-1] + ",tile%d>" % (g.tile_hint - 1)        # side-stream launches: tile shape chosen for running beside others
     if _prof is not None and _prof.shapes:

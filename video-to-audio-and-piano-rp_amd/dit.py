@@ -482,6 +482,8 @@ class DiTEngine:
         p = self.plan
         rows = nseq * p["N"]
         hn, ffh = p[f"hn_{s}"], p[f"ffh_{s}"]
+        # (A row split -- whole 256-row bands on the phase-interleaved kernel in one round, the 28-row tail as its own launch -- takes
+        # the text stream's GEMM from 66.9 to 51 us alone and LOSES 2 % in the sampler, profiles/r03_rowsplit_probe.txt: not done.)
         self._mm([(hn, d, d)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, epilogue=L.EPI_GEGLU, bias=Fw.b1, ldo=ffh.stride(-2),
                  **(dict(out_split=True) if self.split else {}), **in_kw)
         out_kw = dict(out_kw)
