@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--big-tiles", default="", help="A/B: the same table for launches of more than two clips, e.g. a.qkv=0,t.ff2=6")
     ap.add_argument("--side-tiles", default="", help="A/B: per-(stream, op) tile configurations of the side-stream GEMMs, e.g. t.qkv=1,f.ff2=2 (ops: cross qkv out ff1 ff2; -1 = library choice)")
     ap.add_argument("--attn-one-group-from", type=int, default=0, help="A/B: workgroup count from which bf16 attention runs one wave group per workgroup (0 = library default)")
+    ap.add_argument("--cu-masks", default="", help="experiment: 'A,T,F' = CU counts of the audio / text / frames streams (hipExtStreamCreateWithCUMask, "
+                    "disjoint bit ranges); needs --no-graph (a replayed multi-stream hipGraph does not keep stream masks)")
     ap.add_argument("--main-tile", type=int, default=-1, help="A/B: GEMM tile configuration of the audio stream's narrow-output GEMMs (-1 library choice)")
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
@@ -190,6 +192,35 @@ def main():
             log("rank %d: sample %.1f ms, gather %.1f ms" % (rank, (tb - ta) * 1e3, (time.perf_counter() - tb) * 1e3))
         return res
 
+    main_ctx = None
+    if args.cu_masks:
+        import ctypes
+        from v2a_amd import dit as _dit
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        counts = [int(v) for v in args.cu_masks.split(",")]
+        made, lo = [], 0
+        for n in counts:
+            words = (ctypes.c_uint32 * 8)()
+            for b in range(lo, lo + n):
+                words[b // 32] |= 1 << (b % 32)
+            h = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+            assert rc == 0, rc
+            made.append(torch.cuda.ExternalStream(h.value, device=dev))
+            lo += n
+        key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+        cap = _dit.process_streams(dev)[2]
+        _dit._STREAMS[key] = (made[1], made[2], cap)
+        main_ctx = made[0]
+        log("CU masks: audio %d, text %d, frames %d CUs" % tuple(counts))
+        _orig_step = one_step
+        def one_step(steps=cfm_steps):            # the audio stream (sample()'s current stream) is the masked one
+            main_ctx.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(main_ctx):
+                r = _orig_step(steps)
+            torch.cuda.current_stream().wait_stream(main_ctx)
+            return r
     log("model ready: %s, B=%d/GPU, %d-point grid" % (args.dtype, B, cfm_steps))
     for i in range(args.warmup):
         one_step()

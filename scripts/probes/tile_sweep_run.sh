@@ -14,12 +14,13 @@ while read -r spec; do
   echo "[$spec] rc=$rc $v" | tee -a gpurun_out/tile_sweep.txt
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo TIMEOUT; exit 99; fi
 done <<'LIST'
---no-row-split
 _
---no-row-split
-_
---side-tiles a.qkv=12
---no-row-split
+--no-graph
+--no-graph --cu-masks 104,120,32
+--no-graph --cu-masks 112,112,32
+--no-graph --cu-masks 96,128,32
+--no-graph --cu-masks 128,128,0
+--no-graph --cu-masks 256,256,256
 _
 LIST
 cat gpurun_out/tile_sweep.txt
