@@ -164,7 +164,8 @@ typedef struct v2a_tuning {
                                    * the fp32 summation order depend on M): the K loop now walks running pointers */
   int32_t gemm_8phase;            /* 256x256 phase-interleaved kernel for wide outputs (N >= 2048): 0 off, 1 on (staggered wave rows), 2 on (lock-step) */
   int32_t gemm_8phase_min_tiles;  /* ... when the problem yields at least this many 256x256 tiles (0 = 400) */
-  int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass, 4 or 6 (0 = default 4) */
+  int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass of the small-launch kernel, 4 or 6 (0 = default 4);
+                                   * -1 = never use the streaming kernel that chip-filling launches take (A/B) */
   int32_t gemm_xcd_order_1x8;     /* 1: every XCD walks whole column strips of the tile space (the round-1 order) instead of the
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t attn_one_group_from;    /* v2a_attention (bf16): launches with at least this many workgroups run one wave group per workgroup

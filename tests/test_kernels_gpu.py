@@ -339,6 +339,48 @@ def test_gemm_rejects_bad_args(L):
         L.gemm([(a, 40, 40)], w, out, M=4, N=16, compute=L.F32)
 
 
+@pytest.mark.parametrize("B,N,d,ragged", [(16, 782, 1024, False), (16, 782, 1280, True), (16, 782, 512, True), (12, 300, 1024, True), (40, 1500, 96, True)])
+@pytest.mark.parametrize("norm", [None, "bf16", "split"])
+def test_dwconv_streaming_kernel_equals_small_launch_kernel(L, B, N, d, ragged, norm):
+    """Chip-filling launches take the streaming kernel (rows through an LDS ring once per block, taps in registers, deferred stores);
+    it adds the taps in the same order as the per-wave kernel, so the two agree bit for bit -- fp32 rows, the gamma-scaled bf16 (or
+    hi | lo) copy and the sums of squares -- through ragged lengths, partial channel blocks (d = 96) and segment boundaries."""
+    g = _g(B + N + d)
+    x = torch.randn(B, N, d, generator=g).to(DEV)
+    w = (torch.randn(31, d, generator=g) / math.sqrt(31)).to(DEV)
+    bias = (0.1 * torch.randn(d, generator=g)).to(DEV)
+    ld = None
+    if ragged:
+        ld = torch.randint(1, N + 1, (B,), generator=g).to(torch.int32)
+        ld[0], ld[-1] = N, 1
+        ld = ld.to(DEV)
+    res = []
+    for stream in (False, True):
+        L.set_tuning(dwconv_rows_per_wave=0 if stream else -1)
+        out = torch.full((B, N, d), float("nan"), device=DEV)
+        kw = {}
+        if norm:
+            w2 = 2 if norm == "split" else 1
+            hn = torch.zeros(B * N, w2 * d, dtype=torch.bfloat16, device=DEV)
+            ssq = torch.zeros(B * N, (d // 32 + 3) // 4 * 4, device=DEV)
+            gam = (1.0 + 0.3 * torch.randn(B, d, generator=_g(7))).to(DEV)
+            kw = dict(norm=dict(out_bf16=hn, ld_out_bf16=w2 * d, gamma=gam[0], batch_stride=d, ssq=ssq, split=norm == "split"))
+        L.dwconv(x, out, w, bias, B=B, N=N, d=d, ksize=31, lens=ld, **kw)
+        torch.cuda.synchronize()
+        res.append((out, kw["norm"]["out_bf16"], kw["norm"]["ssq"]) if norm else (out,))
+    L.set_tuning()
+    for a, b_ in zip(res[0], res[1]):
+        assert bool(torch.isfinite(a.float()).all())
+        assert torch.equal(a, b_)
+    # and against the definition (x3:495-528 + the residual), fp32
+    lens = ld.cpu() if ld is not None else torch.full((B,), N)
+    m = (torch.arange(N)[None, :] < lens[:, None]).float()[..., None]
+    xm = (x.cpu() * m).transpose(1, 2)
+    conv = torch.nn.functional.conv1d(xm, w.cpu().t()[:, None, :], bias.cpu(), padding=15, groups=d).transpose(1, 2)
+    ref = x.cpu() + m * torch.nn.functional.silu(conv)
+    torch.testing.assert_close(res[1][0].cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
 def test_dwconv_rejects_bad_args(L):
     """The depthwise-conv launch path answers V2A_ERR_ARG for what its kernels are not built for -- before anything reaches the
     runtime (a process abort past the argument checks is what round 2's discarded one-channel-per-lane variant produced)."""

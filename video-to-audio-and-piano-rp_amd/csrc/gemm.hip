@@ -540,6 +540,7 @@ v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 int v2a_detail::g_attn_one_group_from = 1536;
 int v2a_detail::g_probe_dbg = 0;       // v2a_tuning.reserved[0]: read by probe builds only
+int v2a_detail::g_dwconv_stream = 1;   // streaming depthwise conv for chip-filling launches (dwconv_rows_per_wave = -1 switches it off: A/B)
 
 extern "C" int v2a_gemm_args_size(void) { return (int)sizeof(v2a_gemm_args); }
 
@@ -547,17 +548,19 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   if (!t) {
     v2a_detail::g_gemm_tuning = kDefaultTuning;
     v2a_detail::g_dwconv_rows_per_wave = 4;
+    v2a_detail::g_dwconv_stream = 1;
     v2a_detail::g_attn_one_group_from = 1536;
     v2a_detail::g_probe_dbg = 0;
     return V2A_OK;
   }
   // every field is checked before any is assigned: a rejected call leaves the previous tuning whole
-  V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6, "v2a_set_tuning: dwconv_rows_per_wave %d",
-              t->dwconv_rows_per_wave);
+  V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6 || t->dwconv_rows_per_wave == -1,
+              "v2a_set_tuning: dwconv_rows_per_wave %d", t->dwconv_rows_per_wave);
   V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 8 && t->gemm_force_tile != 4, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
   V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
   V2A_REQUIRE(t->gemm_8phase_min_tiles >= 0 && t->attn_one_group_from >= 0, "v2a_set_tuning: negative threshold");
-  v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave ? t->dwconv_rows_per_wave : 4;
+  v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave > 0 ? t->dwconv_rows_per_wave : 4;
+  v2a_detail::g_dwconv_stream = t->dwconv_rows_per_wave == -1 ? 0 : 1;
   v2a_detail::g_attn_one_group_from = t->attn_one_group_from > 0 ? t->attn_one_group_from : 1536;
   v2a_detail::g_gemm_tuning = {t->gemm_force_tile, t->gemm_k_rotation ? 1 : 0, t->gemm_8phase,
                                t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,

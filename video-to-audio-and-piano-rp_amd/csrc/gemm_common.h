@@ -81,6 +81,7 @@ extern GemmTuning g_gemm_tuning;
 extern int g_attn_one_group_from;    // v2a_attention: workgroup count from which one wave group per workgroup is used
 extern int g_dwconv_rows_per_wave;   // 4 or 8 (v2a_set_tuning)
 extern int g_probe_dbg;              // v2a_tuning.reserved[0] (probe builds)
+extern int g_dwconv_stream;          // 0: never use the streaming depthwise conv (v2a_tuning.dwconv_rows_per_wave = -1)
 
 // 256x256 8-phase kernel (gemm_8phase.hip)
 int launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);

@@ -3,8 +3,9 @@
 // kernels (proj_in / proj_frames scatter, register fill, time conditioning).
 // All loads/stores are 16 B per lane on the channel-contiguous (B, N, d) layout.
 #include "v2a_common.h"
+#include <utility>
 
-namespace v2a_detail { extern int g_dwconv_rows_per_wave; }
+namespace v2a_detail { extern int g_dwconv_rows_per_wave; extern int g_dwconv_stream; }
 
 thread_local char v2a_err_buf[512] = {0};
 
@@ -231,6 +232,175 @@ __global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const floa
               bf16x4 ol;
 #pragma unroll
               for (int j = 0; j < 4; ++j) ol[j] = (bf16_t)(o[j] * gm[j] - (float)ob[j]);
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(nrm.out_bf16) + row * nrm.ld_out_bf16 + d + 4 * cc) = ol;
+            }
+            const float ss = octet_sum(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+            if ((lane & 7) == 0) nrm.norm_ssq[row * nrm.ld_norm_ssq + (cc >> 3)] = ss;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Depthwise conv, streaming form for launches that fill the chip (round 3): every input row goes through LDS ONCE per block.
+// The kernel above lets each wave read its own TN + k - 1 rows from global memory per TN outputs -- 8.5x the algorithmic reads
+// at TN = 4, all of them L1 / L2 hits (64 B/clk/CU) that bound it at ~2.5 TB/s of the 8 TB/s (PMC: L2 requests 7.6x the
+// algorithmic reads).  Here a block owns a segment of SEG positions x 256 channels of one sequence.  Wave 4 is a LOADER: it
+// streams the rows by LDS-DMA (global_load_lds_dwordx4: a row piece of 256 channels = one 1 KB wave-instruction, 16 rows per
+// chunk) into a 128-row ring with three chunks (48 KB) in flight; it issues nothing but those DMAs, so its counted
+// `s_waitcnt vmcnt(32)` is exact -- a wave that also stores cannot wait for one of its older DMAs without waiting for the
+// acknowledgement of its freshest stores or counting them (a first version without the loader, one chunk in flight and
+// vmcnt(0) per step, ran at the speed of the kernel above: 16 KB in flight per CU against ~2.5 us of loaded HBM latency).
+// Waves 0-3 read the k + 3 rows of their four outputs from LDS (256 B/clk/CU) with compile-time tap indices, the residual row from
+// the same ring; the k taps of a lane's four channels are split between registers (the first KR) and an LDS copy (the rest, read
+// once per step), which keeps the five waves inside the 256 registers two waves on one SIMD leave each.  One barrier per 16 positions.
+// ------------------------------------------------------------------------------------------
+template <int KS, bool NORM, int NCW>
+__global__ __launch_bounds__(64 * (NCW + 1)) void dwconv_stream_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                            const float* __restrict__ wt, const float* __restrict__ bias,
+                                                            int B, int N, int d, const int32_t* len, int SEG, int nseg, int CB,
+                                                            v2a_dwconv_norm nrm) {
+  constexpr int TO = 16 / NCW;                                                 // outputs per compute wave per chunk (NCW compute waves + one loader)
+  constexpr int HALF = KS / 2, CH = 16, RING_ROWS = 128, WIN = TO + KS - 1;   // chunk rows, ring rows, rows a wave reads per chunk
+  constexpr int KR = 24;                                                       // taps kept in registers; taps KR .. KS-1 live in LDS
+  static_assert(HALF < CH && WIN <= 3 * CH, "window must fit three chunks");
+  extern __shared__ __attribute__((aligned(16))) char ring[];                  // RING_ROWS x 1 KB, then (KS - KR) x 1 KB of taps
+  char* tapl = ring + RING_ROWS * 1024;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // item = (sequence, segment, channel block); channel blocks of one (sequence, segment) are neighbours
+  int item = blockIdx.x;
+  const int cblk = item % CB;
+  item /= CB;
+  const int seg = item % nseg, b = item / nseg;
+  const int p0 = seg * SEG, p1 = min(p0 + SEG, N);
+  const int nch = (p1 - p0 + CH - 1) / CH;           // output chunks of this segment
+  const int w0 = p0 - CH;                            // sequence row of ring row 0: chunk j holds rows w0 + 16 j .. + 15
+  const int c4 = cblk * 64 + lane;
+  const bool cok = c4 * 4 < d;
+  const int cc = cok ? c4 : d / 4 - 1;               // idle lanes shadow a valid channel group; only their stores are masked
+  const int L = len ? min(len[b], N) : N;
+  const float* xb = x + (int64_t)b * N * d;
+
+  if (wave == NCW) {
+    // ---- loader: chunk j -> ring rows (16 j .. 16 j + 15) mod 128
+    const uint32_t loff = (uint32_t)cc * 16u;
+    auto issue = [&](int j) {
+#pragma unroll
+      for (int r = 0; r < CH; ++r) {
+        int row = w0 + CH * j + r;
+        row = row < 0 ? 0 : (row >= N ? N - 1 : row);            // clamped: rows outside the sequence are never multiplied
+        const char* src = reinterpret_cast<const char*>(xb + (int64_t)row * d) + loff;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ring + (((CH * j + r) & (RING_ROWS - 1)) << 10)), 16, 0, 0);
+      }
+    };
+    const int last = nch + 1;                        // last chunk any window touches
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // barrier of step 0: chunks 0 .. 2 are in the ring
+    for (int j = 3; j <= 5; ++j)
+      if (j <= last) issue(j);
+    for (int i = 1; i < nch; ++i) {
+      // chunk i + 2 must have landed; chunks i + 3 and i + 4 (32 DMAs, issued later) may stay in flight.  Near the end fewer
+      // chunks are outstanding and the counted wait would let the needed one through unfinished: wait for everything there.
+      if (i + 4 <= last) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (i + 5 <= last) issue(i + 5);               // ring rows of chunk i - 3: dead since step i - 1
+    }
+    return;
+  }
+
+  // ---- compute waves
+  for (int k = KR + wave; k < KS; k += NCW)            // taps KR .. KS-1 into LDS, one 1 KB row each (visible after the first barrier)
+    *reinterpret_cast<f32x4*>(tapl + (k - KR) * 1024 + lane * 16) = *reinterpret_cast<const f32x4*>(wt + (int64_t)k * d + 4 * cc);
+  f32x4 tap[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) tap[k] = *reinterpret_cast<const f32x4*>(wt + (int64_t)k * d + 4 * cc);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * cc);
+  const float* gmp = NORM ? step_vec(nrm.norm_gamma, nrm.step, nrm.norm_step_stride, nrm.norm_batch_stride, b) + 4 * cc : nullptr;
+  float* ob = out + (int64_t)b * N * d;
+  const char* lbase = ring + lane * 16;
+  const char* tbase = tapl + lane * 16;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS taps are written before the first barrier lets anyone read them
+  for (int i = 0; i < nch; ++i) {
+    __builtin_amdgcn_s_barrier();                    // the loader has waited for chunk i + 2: rows w0 + 16 i .. + 47 are in the ring
+    const int q0 = p0 + CH * i + TO * wave;          // first of this wave's TO outputs
+    const int r0 = q0 - HALF;                        // sequence row of window row 0
+    const int rr0 = r0 - w0;                         // its ring row (before the modulo): 16 i + 4 wave + 1
+    f32x4 acc[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) acc[t] = bv;
+    auto fma_row = [&](auto jc, const f32x4& v) {    // window row j feeds output t through tap j - t (compile-time indices)
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int t = 0; t < TO; ++t) {
+        constexpr int dummy = 0; (void)dummy;
+        const int k = j - t;
+        if (k >= 0 && k < KS) {
+          const f32x4 w = k < KR ? tap[k < KR ? k : 0] : *reinterpret_cast<const f32x4*>(tbase + ((k < KR ? 0 : k - KR) << 10));
+          acc[t] = w * v + acc[t];
+        }
+      }
+    };
+    if (r0 >= 0 && r0 + WIN <= L) {
+      // interior (all but the first and last chunks of a sequence): every window row is valid -- one straight-line block, no
+      // per-row tests (a wave-uniform test per row makes the compiler branch around each row and wait for its LDS read alone)
+      // rows in batches of RB: RB LDS reads in flight, then their FMAs (left alone the compiler reads a row, waits for it and multiplies,
+      // row by row: one exposed LDS latency per row)
+      constexpr int RB = 8;
+      auto batch = [&](auto b0c) {
+        constexpr int B0 = decltype(b0c)::value;
+        f32x4 v[RB];
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+          ((B0 + U < WIN ? (void)(v[U] = *reinterpret_cast<const f32x4*>(lbase + (((rr0 + B0 + U) & (RING_ROWS - 1)) << 10))) : (void)0), ...);
+        }(std::make_integer_sequence<int, RB>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+          ((B0 + U < WIN ? fma_row(std::integral_constant<int, (B0 + U < WIN ? B0 + U : 0)>{}, v[U]) : (void)0), ...);
+        }(std::make_integer_sequence<int, RB>{});
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      [&]<int... Bk>(std::integer_sequence<int, Bk...>) {
+        (batch(std::integral_constant<int, Bk * RB>{}), ...);
+      }(std::make_integer_sequence<int, (WIN + RB - 1) / RB>{});
+    } else {
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        ((r0 + J >= 0 && r0 + J < L   // zero padding and masked rows contribute nothing
+              ? fma_row(std::integral_constant<int, J>{}, *reinterpret_cast<const f32x4*>(lbase + (((rr0 + J) & (RING_ROWS - 1)) << 10)))
+              : (void)0), ...);
+      }(std::make_integer_sequence<int, WIN>{});
+    }
+    if (cok) {
+      f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (NORM) gm = *reinterpret_cast<const f32x4*>(gmp);
+#pragma unroll
+      for (int t = 0; t < TO; ++t) {
+        const int n = q0 + t;
+        if (n < p1) {
+          // the residual row itself (x3:1082: conv(x, mask) + x), unmasked, from the ring: window row HALF + t
+          f32x4 o = *reinterpret_cast<const f32x4*>(lbase + (((rr0 + HALF + t) & (RING_ROWS - 1)) << 10));
+          if (n < L) {
+            // x * sigmoid(x) with v_exp + v_rcp (2 ulp; an IEEE division is ten more instructions per value)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += acc[t][e] * __builtin_amdgcn_rcpf(1.0f + __expf(-acc[t][e]));
+          }
+          *reinterpret_cast<f32x4*>(ob + (int64_t)n * d + 4 * cc) = o;
+          if constexpr (NORM) {
+            const int64_t row = (int64_t)b * N + n;
+            bf16x4 obf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) obf[e] = (bf16_t)(o[e] * gm[e]);
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(nrm.out_bf16) + row * nrm.ld_out_bf16 + 4 * cc) = obf;
+            if (nrm.split) {
+              bf16x4 ol;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ol[e] = (bf16_t)(o[e] * gm[e] - (float)obf[e]);
               *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(nrm.out_bf16) + row * nrm.ld_out_bf16 + d + 4 * cc) = ol;
             }
             const float ss = octet_sum(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
@@ -542,8 +712,36 @@ static int dwconv_launch(const float* x, float* out, const float* wt, const floa
                     ((uintptr_t)norm->out_bf16 & 7) == 0 && ((uintptr_t)norm->norm_gamma & 15) == 0 && norm->norm_step_stride % 4 == 0 &&
                     norm->norm_batch_stride % 4 == 0 && norm->ld_norm_ssq >= d / 32 && (!norm->split || norm->ld_out_bf16 >= 2 * (int64_t)d),
                 "v2a_dwconv: the folded norm needs out_bf16, norm_gamma, norm_ssq, d %% 32 == 0 (d=%d) and aligned rows", d);
-  const int TN = norm ? 4 : v2a_detail::g_dwconv_rows_per_wave;
   const int cb = (d / 4 + 63) / 64;                      // 256-channel blocks
+  hipStream_t s = (hipStream_t)stream;
+  {
+    // streaming form (rows through LDS once per block) when the launch can fill the chip with segments of >= 96 positions:
+    // one workgroup per CU (its registers and the 64 KB ring leave room for no second one)
+    int nseg = (256 + B * cb - 1) / (B * cb);
+    nseg = nseg < 1 ? 1 : nseg;
+    int SEG = ((N + nseg - 1) / nseg + 15) / 16 * 16;
+    if (SEG < 96) SEG = 96;
+    nseg = (N + SEG - 1) / SEG;
+    const int64_t blocks = (int64_t)B * cb * nseg;
+    // ... and only when the one-workgroup-per-CU grid fills its last round (8 clips, d = 1024: 256 blocks, 30.3 us against 39.2 us with
+    // the folded norm; d = 1280 gives 240 blocks of 17 chunks -- 50.7 us against 44.4 us -- and stays on the per-wave kernel)
+    const int64_t rounds = (blocks + 255) / 256;
+    if (v2a_detail::g_dwconv_stream && blocks >= 192 && blocks * 100 >= rounds * 256 * 97 && SEG <= 256) {
+      const v2a_dwconv_norm none{};
+      constexpr size_t smem = (128 + 31 - 24) * 1024;      // the row ring + the taps kept in LDS
+      if (norm) {
+        static std::atomic<uint64_t> lds_set{0};
+        if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(dwconv_stream_kernel<31, true, 8>), smem, lds_set, "v2a_dwconv(stream)")) return rc;
+        hipLaunchKernelGGL((dwconv_stream_kernel<31, true, 8>), dim3((unsigned)blocks), dim3(576), smem, s, x, out, wt, bias, B, N, d, len, SEG, nseg, cb, *norm);
+      } else {
+        static std::atomic<uint64_t> lds_set{0};
+        if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(dwconv_stream_kernel<31, false, 8>), smem, lds_set, "v2a_dwconv(stream)")) return rc;
+        hipLaunchKernelGGL((dwconv_stream_kernel<31, false, 8>), dim3((unsigned)blocks), dim3(576), smem, s, x, out, wt, bias, B, N, d, len, SEG, nseg, cb, none);
+      }
+      return v2a_check_launch("v2a_dwconv_silu_residual(stream)");
+    }
+  }
+  const int TN = norm ? 4 : v2a_detail::g_dwconv_rows_per_wave;
   const int P = (N + 4 * TN - 1) / (4 * TN);             // position tiles of 4 waves x TN outputs
   const int items = P * B, ipx = (items + 7) / 8;        // work items, items per XCD label
   // walkers per XCD label: one per item until the resident blocks per CU (registers: 3 at 4 rows per wave, else 2) are reached,
@@ -555,7 +753,6 @@ static int dwconv_launch(const float* x, float* out, const float* wt, const floa
               "v2a_dwconv: grid does not cover the work (items=%d walkers=%d rounds=%d)", items, walkers, rounds);
   dim3 grid(cb, walkers * 8), block(256);
   const v2a_dwconv_norm none{};
-  hipStream_t s = (hipStream_t)stream;
   // The instantiation that is about to run must be launchable as compiled: 256 threads inside its register budget
   // (__launch_bounds__(256, 3) = 168 VGPRs; a variant that needs more is built with a smaller maxThreadsPerBlock) and its static
   // tap stage inside the 64 KB a kernel gets without opting in.  Asked once per (instantiation, device); a variant that does not
