@@ -15,12 +15,10 @@ while read -r spec; do
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo TIMEOUT; exit 99; fi
 done <<'LIST'
 _
---no-graph
---no-graph --cu-masks 104,120,32
---no-graph --cu-masks 112,112,32
---no-graph --cu-masks 96,128,32
---no-graph --cu-masks 128,128,0
---no-graph --cu-masks 256,256,256
+--steps-per-graph 31
+--steps-per-graph 8
+--steps-per-graph 2
 _
+--steps-per-graph 31
 LIST
 cat gpurun_out/tile_sweep.txt
