@@ -421,11 +421,24 @@ class DiTEngine:
         return (self.fold_norm and self.cd == torch.bfloat16
                 and all(d % 32 == 0 and d <= 1280 for d in (c.dim, c.dim_text, c.dim_frames)))
 
+    def _regime(self):
+        """How a launch of this plan fills the chip, from the tile count of its narrow GEMMs (128x128 tiles over rows x dim) against
+        the 256 CUs: 0 = a launch cannot fill the chip (one clip at the shipped dims: 104 tiles), 1 = about fills it (two clips: 200),
+        2 = fills it several times over.  The per-(stream, op) tile table was measured in regime 0 at the shipped dims only and
+        applies there only; other widths take the stream's default hint or the library's choice."""
+        c = self.cfg
+        tiles = -(-self.plan["rows"] // 128) * max(1, c.dim // 128)
+        return 0 if tiles <= 140 else (1 if tiles <= 281 else 2)
+
+    def _tuned_dims(self):
+        c = self.cfg
+        return (c.dim, c.dim_text, c.dim_frames, c.ff_mult) == (1024, 1280, 512, 4)
+
     def _fold_gemm(self):
         """... into a GEMM epilogue only up to two clips: the extra bf16 row pieces cost an out-projection launch 2 us of 24 at
         one clip (a norm launch: 7.7 us) but 20-26 us of 58 at 8 clips per GPU, more than the 16.5 us norm launch they replace
         (the conv fold wins at every size: 46 us against 49 + 16.5)."""
-        return self._fold() and self.plan["rows"] <= 3200
+        return self._fold() and self._regime() < 2
 
     def _nprod_ada(self, layer, slot, switch_row=0):
         """Producer side of a folded AdaptiveRMSNorm (audio stream): kwargs for the RESID / GATE_RESID GEMM or the conv that
@@ -499,9 +512,10 @@ class DiTEngine:
             return self.split_tiles.get((stream, op), 0)
         if self.side_tile < 0:
             return 0
-        if self.plan["rows"] > 3200:
+        r = self._regime()
+        if r == 2:
             return self.big_tiles.get((stream, op), -1) + 1
-        if self.plan["rows"] > 1600:        # two clips: the table below was tuned at one clip and costs 4 % here (6214 vs 6467)
+        if r == 1 or not self._tuned_dims():        # two clips: the table below was tuned at one clip and costs 4 % here (6214 vs 6467)
             return self.side_tile + 1
         return self.side_tiles.get((stream, op), self.side_tile) + 1
 
@@ -509,10 +523,11 @@ class DiTEngine:
         if self.split:
             t = self.split_tiles.get(("a", op), 0)
             return dict(tile_hint=t) if t else {}
-        if self.plan["rows"] > 3200:
+        r = self._regime()
+        if r == 2:
             t = self.big_tiles.get(("a", op), -1)
             return dict(tile_hint=t + 1) if t >= 0 else {}
-        if self.plan["rows"] > 1600:
+        if r == 1 or not self._tuned_dims():
             return {}
         t = self.side_tiles.get(("a", op), self.main_tile if op in ("x_tfa", "skip", "out", "out2", "ff2") else -1)
         return dict(tile_hint=t + 1) if t >= 0 else {}
