@@ -15,10 +15,10 @@ while read -r spec; do
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo TIMEOUT; exit 99; fi
 done <<'LIST'
 _
---steps-per-graph 31
---steps-per-graph 8
---steps-per-graph 2
+--split-cross
 _
---steps-per-graph 31
+--split-cross
+_
+--split-cross
 LIST
 cat gpurun_out/tile_sweep.txt
