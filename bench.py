@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--big-tiles", default="", help="A/B: the same table for launches of more than two clips, e.g. a.qkv=0,t.ff2=6")
     ap.add_argument("--side-tiles", default="", help="A/B: per-(stream, op) tile configurations of the side-stream GEMMs, e.g. t.qkv=1,f.ff2=2 (ops: cross qkv out ff1 ff2; -1 = library choice)")
     ap.add_argument("--attn-one-group-from", type=int, default=0, help="A/B: workgroup count from which bf16 attention runs one wave group per workgroup (0 = library default)")
+    ap.add_argument("--stream-priority", default="", help="experiment: 'A,S' = HIP stream priorities of the audio (capture) stream and of "
+                    "the two side streams (lower number = higher priority)")
     ap.add_argument("--cu-masks", default="", help="experiment: 'A,T,F' = CU counts of the audio / text / frames streams (hipExtStreamCreateWithCUMask, "
                     "disjoint bit ranges); needs --no-graph (a replayed multi-stream hipGraph does not keep stream masks)")
     ap.add_argument("--main-tile", type=int, default=-1, help="A/B: GEMM tile configuration of the audio stream's narrow-output GEMMs (-1 library choice)")
@@ -193,6 +195,21 @@ def main():
         return res
 
     main_ctx = None
+    if args.stream_priority:
+        # experiment: the audio chain (the graph-capture stream) on a high-priority stream, the side chains on normal / low ones
+        import ctypes
+        from v2a_amd import dit as _dit
+        hip = ctypes.CDLL("libamdhip64.so")
+        lo_p, hi_p = ctypes.c_int(), ctypes.c_int()
+        assert hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo_p), ctypes.byref(hi_p)) == 0
+        pa, ps = (int(v) for v in args.stream_priority.split(","))
+        log("stream priority range: least %d, greatest %d; audio %d, sides %d" % (lo_p.value, hi_p.value, pa, ps))
+        def mk(prio):
+            h = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, prio) == 0      # 1 = hipStreamNonBlocking
+            return torch.cuda.ExternalStream(h.value, device=dev)
+        key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+        _dit._STREAMS[key] = (mk(ps), mk(ps), mk(pa))
     if args.cu_masks:
         import ctypes
         from v2a_amd import dit as _dit
