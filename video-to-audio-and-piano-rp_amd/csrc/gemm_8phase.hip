@@ -26,6 +26,14 @@
 
 namespace {
 
+// probe builds only (scripts/probes/ph8_probe.py): -DV2A_8PH_SKIP=bits drops parts of the steady-state K loop to see which
+// pipe bounds it -- 1 W fragment reads, 2 W half-tile DMAs, 4 A fragment reads, 8 A half-tile DMAs (results are then wrong)
+#if defined(V2A_GEMM_PROBE) && defined(V2A_8PH_SKIP)
+constexpr int kSkip = V2A_8PH_SKIP;
+#else
+constexpr int kSkip = 0;
+#endif
+
 template <int EPI, typename OutT, bool STAGGER>
 __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, TM = 8, TN = 4;
@@ -167,24 +175,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   auto ktile = [&](auto buf_c, int t) {
     constexpr int B = decltype(buf_c)::value;
     // P1
-    read_a(0, B);
-    read_b(0, B, bf0);
+    if (!(kSkip & 4) || t == 0) read_a(0, B);
+    if (!(kSkip & 1) || t == 0) read_b(0, B, bf0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     quadrant(I0{}, I0{}, bf0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // P2
-    read_b(1, B, bf1);
-    if (t + 1 < nk) stage_a(1, t + 1, B ^ 1);
+    if (!(kSkip & 1) || t == 0) read_b(1, B, bf1);
+    if (t + 1 < nk && !(kSkip & 8)) stage_a(1, t + 1, B ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     quadrant(I0{}, I1{}, bf1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // P3
-    read_a(1, B);
-    if (t + 2 < nk) stage_a(0, t + 2, B);
+    if (!(kSkip & 4) || t == 0) read_a(1, B);
+    if (t + 2 < nk && !(kSkip & 8)) stage_a(0, t + 2, B);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     quadrant(I1{}, I1{}, bf1);
@@ -192,8 +200,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     // P4: K tile t+1 (last piece: AH1 from P2) must have landed for every wave before anyone reads it (next P1 and later)
     if (t + 2 < nk) {
-      stage_b(0, t + 2, B);
-      stage_b(1, t + 2, B);
+      if (!(kSkip & 2)) {
+        stage_b(0, t + 2, B);
+        stage_b(1, t + 2, B);
+      }
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
