@@ -247,15 +247,18 @@ __global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const floa
 // Depthwise conv, streaming form for launches that fill the chip (round 3): every input row goes through LDS ONCE per block.
 // The kernel above lets each wave read its own TN + k - 1 rows from global memory per TN outputs -- 8.5x the algorithmic reads
 // at TN = 4, all of them L1 / L2 hits (64 B/clk/CU) that bound it at ~2.5 TB/s of the 8 TB/s (PMC: L2 requests 7.6x the
-// algorithmic reads).  Here a block owns a segment of SEG positions x 256 channels of one sequence.  Wave 4 is a LOADER: it
-// streams the rows by LDS-DMA (global_load_lds_dwordx4: a row piece of 256 channels = one 1 KB wave-instruction, 16 rows per
-// chunk) into a 128-row ring with three chunks (48 KB) in flight; it issues nothing but those DMAs, so its counted
+// algorithmic reads).  Here a block owns a segment of SEG positions x 256 channels of one sequence.  The LAST wave is a LOADER:
+// it streams the rows by LDS-DMA (global_load_lds_dwordx4: a row piece of 256 channels = one 1 KB wave-instruction, 16 rows per
+// chunk) into a 128-row ring (128 KB) with three chunks (48 KB) in flight; it issues nothing but those DMAs, so its counted
 // `s_waitcnt vmcnt(32)` is exact -- a wave that also stores cannot wait for one of its older DMAs without waiting for the
 // acknowledgement of its freshest stores or counting them (a first version without the loader, one chunk in flight and
 // vmcnt(0) per step, ran at the speed of the kernel above: 16 KB in flight per CU against ~2.5 us of loaded HBM latency).
-// Waves 0-3 read the k + 3 rows of their four outputs from LDS (256 B/clk/CU) with compile-time tap indices, the residual row from
-// the same ring; the k taps of a lane's four channels are split between registers (the first KR) and an LDS copy (the rest, read
-// once per step), which keeps the five waves inside the 256 registers two waves on one SIMD leave each.  One barrier per 16 positions.
+// The NCW = 8 compute waves each produce 16 / NCW = 2 outputs per chunk: they read the k + 1 rows of their outputs from LDS
+// (256 B/clk/CU) with compile-time tap indices, in batches of 8 rows, and the residual rows from the same ring.  Chunks whose
+// window lies inside the sequence take a straight-line path with no per-row test (a wave-uniform test per row makes the
+// compiler branch around every LDS read and serialises them: measured 2x slower); the first and last steps of a sequence take
+// the tested path.  The k taps of a lane's four channels are split between registers (the first KR = 24) and an LDS copy (the
+// rest), which keeps a compute wave inside the 256 registers two waves on one SIMD leave each.  One barrier per 16 positions.
 // ------------------------------------------------------------------------------------------
 template <int KS, bool NORM, int NCW>
 __global__ __launch_bounds__(64 * (NCW + 1)) void dwconv_stream_kernel(const float* __restrict__ x, float* __restrict__ out,
