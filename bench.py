@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--interleave-capture", type=int, default=-1, help="A/B: 1 = interleave the capture order of audio and side blocks")
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
     ap.add_argument("--no-fuse-skip", action="store_true", help="A/B: cross-condition and skip projection as two GEMMs")
+    ap.add_argument("--no-fuse-xattn", action="store_true", help="A/B: q-projection and cross-attention of the audio stream as two launches")
     ap.add_argument("--no-fold-norm", action="store_true", help="A/B: separate RMSNorm launches instead of folding them into the neighbouring kernels")
     ap.add_argument("--big-tiles", default="", help="A/B: the same table for launches of more than two clips, e.g. a.qkv=0,t.ff2=6")
     ap.add_argument("--side-tiles", default="", help="A/B: per-(stream, op) tile configurations of the side-stream GEMMs, e.g. t.qkv=1,f.ff2=2 (ops: cross qkv out ff1 ff2; -1 = library choice)")
@@ -167,6 +168,8 @@ def main():
         model.engine().fold_norm = False
     if args.no_fuse_skip:
         model.engine().fuse_skip = False
+    if args.no_fuse_xattn:
+        model.engine().fuse_xattn = False
     model.engine().cross_on_main = args.cross_on_main
     if args.interleave_capture >= 0:
         model.engine().interleave_capture = bool(args.interleave_capture)

@@ -51,7 +51,7 @@ enum {
   V2A_ERR_LAUNCH = -2  /* hipGetLastError() after launch */
 };
 
-int v2a_abi_version(void);        /* 5 */
+int v2a_abi_version(void);        /* 6 */
 const char* v2a_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -254,6 +254,20 @@ typedef struct v2a_attn_args {
 } v2a_attn_args;
 
 int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Cross-attention of the audio stream in ONE launch (ABI 6): the q-projection GEMM of v2a_gemm -- STORE epilogue with the optional
+ * row_ssq consumer scale, bias and fused RoPE -- whose 64-token x one-head output tile never leaves the workgroup: it is the Q
+ * operand of QK^T over the clip's Nk <= 64 context keys, soft clamp, softmax, PV, per-head sigmoid gate, and only the attention
+ * output rows are written.  Equal bit for bit to v2a_gemm(gemm) into a [q | gate] buffer followed by v2a_attention(attn) on it.
+ *   gemm: nseg = 1, bf16 A and W, ka[0] a multiple of 512; W rows [0, H*64) = to_q, rows [H*64, H*64 + H) = the per-head gate
+ *         rows (N >= H*65), bias likewise; M = attn->B * attn->Nq rows, rows_per_batch = attn->Nq; out / ldo / out_dtype ignored.
+ *   attn: dtype V2A_BF16; k, v, out and their strides, B, H, Nq, Nk, kv_len, q_len, scale, softclamp as for v2a_attention;
+ *         q, gate and their strides ignored.
+ * Replaces: xt Attention.forward with a context -- to_q, rotary_emb on q, attend, to_v_gates -- at call site x3:1126 (audio
+ * stream of a layer with text context), for launches small enough to be latency bound (the sampler: <= 2 clips per GPU).
+ * ------------------------------------------------------------------------------------- */
+int v2a_qproj_xattn(const v2a_gemm_args* gemm, const v2a_attn_args* attn, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Small fp32 linear with output row scatter (K arbitrary, VALU):

@@ -217,3 +217,27 @@ def test_config4_cascade_equals_independent_calls(full, mbf):
         assert torch.equal(ind, casc[i]), f"pass {i}: cascade differs from an independent call"
         del fresh
     assert not torch.equal(casc[0], casc[1])
+
+
+@pytest.mark.parametrize("clips,ragged", [(1, False), (2, True)])
+def test_bf16_one_launch_cross_attention_equals_two_launches(full, mbf, clips, ragged):
+    """bf16 mode, up to two clips: q-projection + cross-attention as one launch (`engine().fuse_xattn`, v2a_qproj_xattn) against the
+    GEMM into the [q | gate] buffer followed by v2a_attention -- the same arithmetic, so the sampled latents are equal bit for bit
+    (ragged clip lengths and context lengths included)."""
+    f = full
+    cfg = f["cfg"]
+    y0, text, roll, ctx, cm = O.synthetic_inputs(cfg, clips, 750, nc=16, seed=3)
+    kw = dict(y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, return_raw_output=True, steps=4, cfg_strength=2.0,
+              remove_parallel_component=False)
+    if ragged:
+        cm = cm.clone()
+        cm[1, 9:] = False
+        kw.update(context_mask=cm, lens=torch.tensor([750, 611]), duration=torch.tensor([750, 611]))
+    outs, launches = [], []
+    for fuse in (True, False):
+        eng = mbf.engine()
+        eng.fuse_xattn = fuse
+        outs.append(mbf.sample(torch.zeros(clips, 750, 128), **kw).float().cpu())
+    mbf.engine().fuse_xattn = True
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())

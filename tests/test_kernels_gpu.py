@@ -1029,3 +1029,60 @@ def test_gemm_tile_hint_three_segments_bitwise(L, hint, ks):
     L.gemm(a3, w3, ref, tile_hint=4, **kw)
     L.gemm(a3, w3, got, tile_hint=hint, **kw)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("B,Nq,Nk,kv_len,q_len", [(1, 782, 32, [20], [782]), (2, 782, 32, [32, 1], [782, 500]), (3, 100, 64, [64, 33, 0], [100, 64, 1]),
+                                                  (2, 64, 5, [5, 3], [64, 10]), (1, 44, 16, None, None)])
+@pytest.mark.parametrize("H,K", [(16, 1024), (3, 512)])
+@pytest.mark.parametrize("clamp", [50.0, 80.0, 0.0])
+@pytest.mark.parametrize("folded,rope", [(True, True), (False, False)])
+def test_qproj_xattn_equals_two_launches(L, B, Nq, Nk, kv_len, q_len, H, K, clamp, folded, rope):
+    """v2a_qproj_xattn (q-projection + RoPE + cross-attention + head gate in one launch) == v2a_gemm into a [q | gate] buffer followed
+    by v2a_attention, bit for bit: sequences that end inside a 64-row tile, ragged query / key lengths (one clip without keys),
+    every clamp mode, with and without the folded-RMSNorm row scale and the fused RoPE."""
+    g = _g(B * Nq + Nk + H)
+    M, inner, N = B * Nq, H * 64, H * 64 + 16
+    a = (torch.randn(M, K, generator=g) * 0.7).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K) * 3.0).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    kv = (torch.randn(B, Nk, 2 * inner, generator=g) * 1.5).bfloat16().to(DEV)
+    tab = _rope_table(Nq + 5).to(DEV) if rope else None
+    ssq = None
+    if folded:
+        ssq = torch.zeros(M, 40, device=DEV)
+        ssq[:, :K // 32] = (torch.rand(M, K // 32, generator=g) * 30 + 5).to(DEV)
+    kvl = torch.tensor(kv_len, dtype=torch.int32, device=DEV) if kv_len is not None else None
+    ql = torch.tensor(q_len, dtype=torch.int32, device=DEV) if q_len is not None else None
+    rk = dict(rope_table=tab, rope_cols=inner, rope_pos_offset=2) if rope else {}
+    nk = dict(row_ssq=ssq, row_norm_dim=K) if folded else {}
+    # two launches
+    qb = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm([(a, K, K)], w, qb, M=M, N=N, compute=L.BF16, bias=bias, rows_per_batch=Nq, tile_hint=4, **rk, **nk)
+    ref = torch.full((B, Nq, inner), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.attention(qb.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, qb.data_ptr() + inner * 2, ref.data_ptr(),
+                strides=(N, 2 * inner, 2 * inner, N, inner, Nq * N, Nk * 2 * inner, Nk * 2 * inner, Nq * N, Nq * inner),
+                B=B, H=H, Nq=Nq, Nk=Nk, kv_len=kvl, q_len=ql, scale=0.125, softclamp=clamp, dtype=L.BF16)
+    # one launch
+    got = torch.full((B, Nq, inner), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.qproj_xattn(a, K, K, w, bias=bias, M=M, N=N, rows_per_batch=Nq, k=kv.data_ptr(), v=kv.data_ptr() + inner * 2, out=got.data_ptr(),
+                  kv_strides=(2 * inner, 2 * inner, Nk * 2 * inner, Nk * 2 * inner), out_strides=(inner, Nq * inner), B=B, H=H, Nk=Nk,
+                  kv_len=kvl, q_len=ql, scale=0.125, softclamp=clamp, **rk, **nk)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref.float()).all()
+    assert ref.float().abs().max() > 0.05
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
+
+
+def test_qproj_xattn_rejects_bad_args(L):
+    a = torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(65, 512, dtype=torch.bfloat16, device=DEV)
+    kv = torch.zeros(1, 80, 128, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(1, 64, 64, dtype=torch.bfloat16, device=DEV)
+    base = dict(bias=None, M=64, N=65, rows_per_batch=64, k=kv.data_ptr(), v=kv.data_ptr() + 128, out=out.data_ptr(), kv_strides=(128, 128, 80 * 128, 80 * 128),
+                out_strides=(64, 64 * 64), B=1, H=1, Nk=16, scale=0.125, softclamp=50.0)
+    L.qproj_xattn(a, 512, 512, w, **base)
+    for bad in (dict(Nk=65), dict(N=64), dict(M=63), dict(rows_per_batch=32)):
+        with pytest.raises(L.V2AError):
+            L.qproj_xattn(a, 512, 512, w, **{**base, **bad})
+    with pytest.raises(L.V2AError):
+        L.qproj_xattn(a, 512, 320, w, **base)          # K not a multiple of 512

@@ -85,7 +85,7 @@ class RollHeadArgs(C.Structure):
 
 EXPORTS = [
     "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual", "v2a_dwconv_silu_residual_norm",
-    "v2a_rope_inplace", "v2a_attention", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
+    "v2a_rope_inplace", "v2a_attention", "v2a_qproj_xattn", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16", "v2a_split_bf16",
     "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
     "v2a_elu_pad", "v2a_lstm_layer", "v2a_lstm2",
@@ -106,7 +106,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-ABI_VERSION = 5          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
+ABI_VERSION = 6          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
 
 
 def _declare(lib):
@@ -117,6 +117,7 @@ def _declare(lib):
     lib.v2a_gemm_args_size.restype = C.c_int
     lib.v2a_set_tuning.argtypes = [C.POINTER(Tuning)]
     lib.v2a_attention.argtypes = [C.POINTER(AttnArgs), vp]
+    lib.v2a_qproj_xattn.argtypes = [C.POINTER(GemmArgs), C.POINTER(AttnArgs), vp]
     lib.v2a_rmsnorm.argtypes = [vp, i64, vp, i64, i32, i64, i32, vp, vp, i64, i64, i32, vp]
     lib.v2a_dwconv_silu_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.v2a_dwconv_silu_residual_norm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, C.POINTER(DwconvNorm), vp]
@@ -395,6 +396,37 @@ def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=N
     esz = 2 if dtype == BF16 else 4
     _launch("attention<%s>" % {BF16: "bf16", F32: "f32", BF16_SPLIT: "bf16x3"}[dtype], 4.0 * B * H * Nq * Nk * 64,
             B * H * 64 * (2 * Nq + 2 * Nk) * esz, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
+
+
+def qproj_xattn(a, lda, K, w, *, bias, M, N, rows_per_batch, k, v, out, kv_strides, out_strides, B, H, Nk, kv_len=None, q_len=None,
+                scale, softclamp, rope_table=None, rope_cols=0, rope_pos_offset=0, row_ssq=None, row_norm_dim=0):
+    """q-projection + cross-attention in one launch (v2a_qproj_xattn).  a: (M, K) bf16 rows; w: [N >= H*65][K] = to_q rows then the
+    gate rows; k, v, out: integer device addresses; kv_strides = (k_row, v_row, k_batch, v_batch), out_strides = (row, batch)."""
+    g = GemmArgs()
+    g.a[0], g.lda[0], g.ka[0], g.nseg = a.data_ptr(), lda, K, 1
+    g.a_dtype = g.compute_dtype = BF16
+    g.w, g.ldw = w.data_ptr(), w.stride(0)
+    g.bias = _p(bias)
+    g.M, g.N = M, N
+    g.epilogue = EPI_STORE
+    g.out_dtype = BF16
+    g.rows_per_batch = rows_per_batch
+    g.rope_table = _p(rope_table)
+    g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
+    g.row_ssq = _p(row_ssq)
+    g.ld_row_ssq = row_ssq.stride(-2) if row_ssq is not None else 0
+    g.row_ssq_parts = row_norm_dim // 32 if row_ssq is not None else 0
+    g.row_norm_dim = row_norm_dim
+    t = AttnArgs()
+    t.k, t.v, t.out = k, v, out
+    t.k_row_stride, t.v_row_stride, t.k_batch_stride, t.v_batch_stride = kv_strides
+    t.out_row_stride, t.out_batch_stride = out_strides
+    t.B, t.H, t.Nq, t.Nk = B, H, rows_per_batch, Nk
+    t.kv_len, t.q_len = _p(kv_len), _p(q_len)
+    t.scale, t.softclamp, t.dtype = scale, softclamp, BF16
+    _launch("qproj_xattn", 2.0 * M * (H * 65) * K + 4.0 * B * H * rows_per_batch * Nk * 64,
+            M * K * 2 + H * 65 * K * 2 + M * H * 64 * 2 + 2 * B * Nk * H * 64 * 2,
+            lambda: lib().v2a_qproj_xattn(C.byref(g), C.byref(t), stream_ptr()))
 
 
 def linear_small(a, wt, bias, add, out, *, M, K, T, out_batch_stride, row_off, d, dup=0, regs=None, out_bf16=None):

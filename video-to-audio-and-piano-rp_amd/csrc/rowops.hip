@@ -9,7 +9,7 @@ namespace v2a_detail { extern int g_dwconv_rows_per_wave; extern int g_dwconv_st
 
 thread_local char v2a_err_buf[512] = {0};
 
-extern "C" int v2a_abi_version(void) { return 5; }
+extern "C" int v2a_abi_version(void) { return 6; }
 extern "C" const char* v2a_last_error(void) { return v2a_err_buf; }
 
 namespace {

@@ -259,6 +259,9 @@ class DiTEngine:
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
+        # bf16 mode, up to two clips: the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
+        # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
+        self.fuse_xattn = True
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
@@ -375,7 +378,7 @@ class DiTEngine:
         the tuning knobs on this object and the per-call state prepare() leaves in the plan."""
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
-                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.cross_on_main,
+                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
                 self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
@@ -814,7 +817,20 @@ class DiTEngine:
                 if not fold2:
                     self._norm_ada(x, p["hn_a"], r2, D, i, 1)
                 q2 = p["q2"]
-                if self.rope_cross and self._fuse_rope:
+                es = q2.element_size()
+                kb = p["ctx_kv"].data_ptr() + i * inner * es
+                vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
+                aw = p["ao_a"].stride(-2)
+                one_launch = (self.fuse_xattn and self.adc == L.BF16 and not self.split and self._regime() <= 1 and p["nc"] <= 64 and D % 512 == 0
+                              and A2.gate_col == A2.inner and (self._fuse_rope or not self.rope_cross))
+                if one_launch:
+                    rk = dict(rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0) if self.rope_cross else {}
+                    nk = dict(row_ssq=cons2["row_ssq"], row_norm_dim=cons2["row_norm_dim"]) if cons2 else {}
+                    L.qproj_xattn(p["hn_a"], D, D, A2.w_in, bias=A2.b_in, M=r2, N=A2.n_pad, rows_per_batch=N, k=kb, v=vb, out=p["ao_a"].data_ptr(),
+                                  kv_strides=(nkv, nkv, p["nc"] * nkv, p["nc"] * nkv), out_strides=(aw, N * aw), B=nctx, H=A2.heads, Nk=p["nc"],
+                                  kv_len=p["ctx_len"], q_len=lens if self.zero_masked_queries else None, scale=c.dim_head ** -0.5,
+                                  softclamp=self.softclamp, **rk, **nk)
+                elif self.rope_cross and self._fuse_rope:
                     self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad,
                              rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons2, **mh("q2"))
                 else:
@@ -822,16 +838,13 @@ class DiTEngine:
                     if self.rope_cross:
                         L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
                                table=p["rope"], layout=self.rope_layout)
-                es = q2.element_size()
-                kb = p["ctx_kv"].data_ptr() + i * inner * es
-                vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
-                aw = p["ao_a"].stride(-2)
-                L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, p["ao_a"].data_ptr(),
-                            strides=(A2.n_pad, nkv, nkv, A2.n_pad, aw,
-                                     N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * aw),
-                            B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
-                            q_len=lens if self.zero_masked_queries else None,
-                            scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
+                if not one_launch:
+                    L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, p["ao_a"].data_ptr(),
+                                strides=(A2.n_pad, nkv, nkv, A2.n_pad, aw,
+                                         N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * aw),
+                                B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
+                                q_len=lens if self.zero_masked_queries else None,
+                                scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
                 prod2 = {}
                 if fold2:
                     n2 = {k: v for k, v in self._nprod_ada(i, 2).items() if k not in ("step", "rows_per_batch")}
