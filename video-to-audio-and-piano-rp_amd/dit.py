@@ -855,6 +855,8 @@ class DiTEngine:
                 self._norm_ada(x, p["hn_a"], rows, D, i, 2)
             # the bf16 copy of this layer's output: into the wide buffer of the next layer's skip when that layer is fused
             xsh = dict(out_bf16=p["wide"][c.depth - 2 - i][..., :D]) if (fz and half <= i + 1 < c.depth) else {}
+            if last and fold2:      # the final RMSNorm folded like the others: gamma on the operand copy, 1 / rms per row in to_pred's epilogue
+                xsh = dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), norm_gamma=W.final_g, norm_ssq=p["ssq_a"])
             self._ff(ly["a_ff"], x, "a", Bt, D, dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2), **mh("ff2"), **xsh), dict(**cons2, **mh("ff1")))
             if not last:
                 if not self.cross_on_main:
@@ -877,8 +879,11 @@ class DiTEngine:
                 tc_, fc_ = tbuf[1], fbuf[1]
             xc, xo = xo, xc
         # final norm over all rows (registers are dropped by the consumer) + to_pred (x3:1141-1143, 2083)
-        L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g, split=self.split)
-        self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels)
+        if self._fold_gemm():
+            self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels, **self._ncons("a", D))
+        else:
+            L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g, split=self.split)
+            self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels)
         return p["pred"]
 
     def euler_step(self, y, cfg_strength: float, remove_parallel_component: bool = False, keep_parallel_frac: float = 0.0):
