@@ -68,7 +68,7 @@ def main():
                       kv_strides=(2 * inner, 2 * inner, Nk * 2 * inner, Nk * 2 * inner), out_strides=(inner, Nq * inner), B=B, H=H, Nk=Nk,
                       kv_len=kvl, q_len=None, scale=0.125, softclamp=50.0, **rk, **nk)
 
-    for tile in (3, 14):
+    for tile in (3, 14, -1, 6):
         tg = time_graph(lambda: gemm(tile))
         tb = time_graph(lambda: (gemm(tile), attn()))
         print(f"{B} clip(s): q-projection on tile {tile:2d} {tg:6.2f} us; + attention {tb:6.2f} us", flush=True)
