@@ -12,13 +12,19 @@ import torch  # noqa: E402
 import v2a_amd  # noqa: E402,F401
 from v2a_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+MODE = None
+if sys.argv[1].startswith("mode"):          # "mode1" / "mode2" / "mode3": the shipped library with v2a_tuning.gemm_8phase = 1 / 2 / 3
+    MODE = int(sys.argv[1][4:])
+else:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 DEV = torch.device("cuda:0")
 REPS = 20
 
 
 def main():
     specs = sys.argv[2:] or ["12512x8192x1024:geglu", "12512x1024x4096:resid", "12512x3088x1024:store", "1564x8192x1024:geglu", "12512x8192x4096:geglu"]
+    if MODE is not None:
+        _lib.set_tuning(eight_phase=MODE)
     for spec in specs:
         shp, epi = spec.split(":")
         M, N, K = (int(v) for v in shp.split("x"))
