@@ -219,8 +219,9 @@ def test_config4_cascade_equals_independent_calls(full, mbf):
     assert not torch.equal(casc[0], casc[1])
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("clips,ragged", [(1, False), (2, True)])
-def test_bf16_one_launch_cross_attention_equals_two_launches(full, mbf, clips, ragged):
+def test_bf16_one_launch_cross_attention_equals_two_launches(full, mbf, clips, ragged, mode):
     """bf16 mode, up to two clips: q-projection + cross-attention as one launch (`engine().fuse_xattn`, v2a_qproj_xattn) against the
     GEMM into the [q | gate] buffer followed by v2a_attention -- the same arithmetic, so the sampled latents are equal bit for bit
     (ragged clip lengths and context lengths included)."""
@@ -233,11 +234,11 @@ def test_bf16_one_launch_cross_attention_equals_two_launches(full, mbf, clips, r
         cm = cm.clone()
         cm[1, 9:] = False
         kw.update(context_mask=cm, lens=torch.tensor([750, 611]), duration=torch.tensor([750, 611]))
-    outs, launches = [], []
+    m = mbf if mode == "bf16" else make_model(f["cfg"], f["P"], "bf16x3")
+    outs = []
     for fuse in (True, False):
-        eng = mbf.engine()
-        eng.fuse_xattn = fuse
-        outs.append(mbf.sample(torch.zeros(clips, 750, 128), **kw).float().cpu())
-    mbf.engine().fuse_xattn = True
+        m.engine().fuse_xattn = fuse
+        outs.append(m.sample(torch.zeros(clips, 750, 128), **kw).float().cpu())
+    m.engine().fuse_xattn = True
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())

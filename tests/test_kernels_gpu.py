@@ -1073,6 +1073,45 @@ def test_qproj_xattn_equals_two_launches(L, B, Nq, Nk, kv_len, q_len, H, K, clam
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
 
 
+@pytest.mark.parametrize("B,Nq,Nk,kv_len,q_len", [(1, 782, 16, [11], [782]), (2, 782, 32, [32, 1], [782, 500]), (3, 100, 64, [64, 33, 0], [100, 64, 1])])
+@pytest.mark.parametrize("clamp", [50.0, 80.0, 0.0])
+@pytest.mark.parametrize("folded,rope", [(True, True), (False, False)])
+def test_qproj_xattn_split_equals_two_launches(L, B, Nq, Nk, kv_len, q_len, clamp, folded, rope):
+    """bf16x3 arithmetic: v2a_qproj_xattn on split operands == the split GEMM into an fp32 [q | gate] buffer followed by v2a_attention
+    (dtype V2A_BF16_SPLIT, out_split), bit for bit -- and within 2e-4 of the fp32 reference."""
+    H, K = 16, 1024
+    g = _g(7 * B * Nq + Nk)
+    M, inner, N = B * Nq, H * 64, H * 64 + 16
+    a32 = torch.randn(M, K, generator=g) * 0.7
+    w32 = torch.randn(N, K, generator=g) / math.sqrt(K) * 3.0
+    a = _split_planes(a32).to(DEV)
+    w = _split_planes(w32).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    kv = (torch.randn(B, Nk, 2 * inner, generator=g) * 1.5).to(DEV)
+    tab = _rope_table(Nq + 5).to(DEV) if rope else None
+    ssq = None
+    if folded:
+        ssq = torch.zeros(M, 40, device=DEV)
+        ssq[:, :K // 32] = (torch.rand(M, K // 32, generator=g) * 30 + 5).to(DEV)
+    kvl = torch.tensor(kv_len, dtype=torch.int32, device=DEV)
+    ql = torch.tensor(q_len, dtype=torch.int32, device=DEV)
+    rk = dict(rope_table=tab, rope_cols=inner, rope_pos_offset=2) if rope else {}
+    nk = dict(row_ssq=ssq, row_norm_dim=K) if folded else {}
+    qb = torch.zeros(M, N, device=DEV)
+    L.gemm([(a, 2 * K, K)], w, qb, M=M, N=N, compute=L.BF16, bias=bias, rows_per_batch=Nq, a_split=True, tile_hint=1, **rk, **nk)
+    ref = torch.full((B, Nq, 2 * inner), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.attention(qb.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 4, qb.data_ptr() + inner * 4, ref.data_ptr(),
+                strides=(N, 2 * inner, 2 * inner, N, 2 * inner, Nq * N, Nk * 2 * inner, Nk * 2 * inner, Nq * N, Nq * 2 * inner),
+                B=B, H=H, Nq=Nq, Nk=Nk, kv_len=kvl, q_len=ql, scale=0.125, softclamp=clamp, dtype=L.BF16_SPLIT, out_split=True)
+    got = torch.full((B, Nq, 2 * inner), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.qproj_xattn(a, 2 * K, K, w, bias=bias, M=M, N=N, rows_per_batch=Nq, k=kv.data_ptr(), v=kv.data_ptr() + inner * 4, out=got.data_ptr(),
+                  kv_strides=(2 * inner, 2 * inner, Nk * 2 * inner, Nk * 2 * inner), out_strides=(2 * inner, Nq * 2 * inner), B=B, H=H, Nk=Nk,
+                  kv_len=kvl, q_len=ql, scale=0.125, softclamp=clamp, split=True, **rk, **nk)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref.float()).all() and ref.float().abs().max() > 0.05
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
+
+
 def test_qproj_xattn_rejects_bad_args(L):
     a = torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV)
     w = torch.zeros(65, 512, dtype=torch.bfloat16, device=DEV)

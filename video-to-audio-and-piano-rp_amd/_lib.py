@@ -399,17 +399,19 @@ def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=N
 
 
 def qproj_xattn(a, lda, K, w, *, bias, M, N, rows_per_batch, k, v, out, kv_strides, out_strides, B, H, Nk, kv_len=None, q_len=None,
-                scale, softclamp, rope_table=None, rope_cols=0, rope_pos_offset=0, row_ssq=None, row_norm_dim=0):
+                scale, softclamp, rope_table=None, rope_cols=0, rope_pos_offset=0, row_ssq=None, row_norm_dim=0, split=False):
     """q-projection + cross-attention in one launch (v2a_qproj_xattn).  a: (M, K) bf16 rows; w: [N >= H*65][K] = to_q rows then the
-    gate rows; k, v, out: integer device addresses; kv_strides = (k_row, v_row, k_batch, v_batch), out_strides = (row, batch)."""
+    gate rows; k, v, out: integer device addresses; kv_strides = (k_row, v_row, k_batch, v_batch), out_strides = (row, batch).
+    split=True (bf16x3 mode): a rows = [hi K | lo K], w rows = [W_hi | W_lo], k / v fp32, out rows = hi | lo planes (2 * H * 64 bf16)."""
     g = GemmArgs()
     g.a[0], g.lda[0], g.ka[0], g.nseg = a.data_ptr(), lda, K, 1
-    g.a_dtype = g.compute_dtype = BF16
+    g.compute_dtype = BF16
+    g.a_dtype = BF16_SPLIT if split else BF16
     g.w, g.ldw = w.data_ptr(), w.stride(0)
     g.bias = _p(bias)
     g.M, g.N = M, N
     g.epilogue = EPI_STORE
-    g.out_dtype = BF16
+    g.out_dtype = F32 if split else BF16
     g.rows_per_batch = rows_per_batch
     g.rope_table = _p(rope_table)
     g.rope_cols, g.rope_pos_offset = rope_cols, rope_pos_offset
@@ -423,8 +425,9 @@ def qproj_xattn(a, lda, K, w, *, bias, M, N, rows_per_batch, k, v, out, kv_strid
     t.out_row_stride, t.out_batch_stride = out_strides
     t.B, t.H, t.Nq, t.Nk = B, H, rows_per_batch, Nk
     t.kv_len, t.q_len = _p(kv_len), _p(q_len)
-    t.scale, t.softclamp, t.dtype = scale, softclamp, BF16
-    _launch("qproj_xattn", 2.0 * M * (H * 65) * K + 4.0 * B * H * rows_per_batch * Nk * 64,
+    t.scale, t.softclamp, t.dtype = scale, softclamp, (BF16_SPLIT if split else BF16)
+    t.out_split = 1 if split else 0
+    _launch("qproj_xattn<%s>" % ("bf16x3" if split else "bf16"), (3.0 if split else 1.0) * (2.0 * M * (H * 65) * K + 4.0 * B * H * rows_per_batch * Nk * 64),
             M * K * 2 + H * 65 * K * 2 + M * H * 64 * 2 + 2 * B * Nk * H * 64 * 2,
             lambda: lib().v2a_qproj_xattn(C.byref(g), C.byref(t), stream_ptr()))
 

@@ -259,7 +259,7 @@ class DiTEngine:
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
-        # bf16 mode, up to three clips (stand-alone 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
+        # bf16 and bf16x3 modes, up to three clips (bf16 stand-alone: 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
         # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
         self.fuse_xattn = True
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
@@ -821,12 +821,13 @@ class DiTEngine:
                 kb = p["ctx_kv"].data_ptr() + i * inner * es
                 vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
                 aw = p["ao_a"].stride(-2)
-                one_launch = (self.fuse_xattn and self.adc == L.BF16 and not self.split and r2 <= 2400 and p["nc"] <= 64 and D % 512 == 0
+                one_launch = (self.fuse_xattn and self.adc in (L.BF16, L.BF16_SPLIT) and r2 <= 2400 and p["nc"] <= 64 and D % 512 == 0
                               and A2.gate_col == A2.inner and (self._fuse_rope or not self.rope_cross))
                 if one_launch:
                     rk = dict(rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0) if self.rope_cross else {}
                     nk = dict(row_ssq=cons2["row_ssq"], row_norm_dim=cons2["row_norm_dim"]) if cons2 else {}
-                    L.qproj_xattn(p["hn_a"], D, D, A2.w_in, bias=A2.b_in, M=r2, N=A2.n_pad, rows_per_batch=N, k=kb, v=vb, out=p["ao_a"].data_ptr(),
+                    L.qproj_xattn(p["hn_a"], p["hn_a"].stride(-2) if self.split else D, D, A2.w_in, bias=A2.b_in, M=r2, N=A2.n_pad, rows_per_batch=N,
+                                  k=kb, v=vb, out=p["ao_a"].data_ptr(), split=self.split,
                                   kv_strides=(nkv, nkv, p["nc"] * nkv, p["nc"] * nkv), out_strides=(aw, N * aw), B=nctx, H=A2.heads, Nk=p["nc"],
                                   kv_len=p["ctx_len"], q_len=lens if self.zero_masked_queries else None, scale=c.dim_head ** -0.5,
                                   softclamp=self.softclamp, **rk, **nk)
