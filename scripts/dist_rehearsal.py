@@ -55,13 +55,21 @@ def main():
 
     s, e, per = v2a_amd.shard_range(n_clips, rank, world)
     t0 = time.time()
+    reps = []
     for rep in range(2):                       # second pass: plan + graph cache hit, replay next to a live process group
         mine = run(s, e) if e > s else torch.zeros(0, T, cfg.num_channels, device=dev)
+        reps.append(mine.clone())
         got = v2a_amd.gather_latents(mine, n_clips, per)
     t1 = time.time()
     assert got.shape == (n_clips, T, cfg.num_channels) and bool(torch.isfinite(got).all())
     whole = run(0, n_clips)                    # the same clips as ONE single-process batch
     d = float((got - whole).abs().max())
+    if d != 0.0:                               # say where: which clips, which pass, own shard or the other rank's
+        per_clip = [float((got[i] - whole[i]).abs().max()) for i in range(n_clips)]
+        print(f"rank {rank}: per-clip max |delta| gathered vs whole {per_clip}; pass 0 vs pass 1 of the own shard "
+              f"{float((reps[0] - reps[1]).abs().max()) if e > s else 0.0:.3e}; own shard (pass 1) vs whole "
+              f"{float((reps[1] - whole[s:e]).abs().max()) if e > s else 0.0:.3e}; (pass 0) {float((reps[0] - whole[s:e]).abs().max()) if e > s else 0.0:.3e}",
+              flush=True)
     # batch-size independence: fp32 / bf16x3 results are bit-equal; bf16 GEMMs may pick another tile shape for another row
     # count, which keeps every element's K order -- equal as well
     print(f"rank {rank}/{world} [{mode}] device {dev} backend {dist.get_backend() if world > 1 else 'none'}: shard [{s},{e}) of {n_clips} clips, "

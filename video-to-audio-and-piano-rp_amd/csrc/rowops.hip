@@ -479,31 +479,40 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
                                                            int T, float* __restrict__ out, int64_t obs, int row_off, int d,
                                                            int dup, const float* __restrict__ regs, bf16_t* __restrict__ out2) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* as = reinterpret_cast<float*>(smem_raw);  // [ROWS][K]
+  // A rows in LDS as (a, a) PAIRS, [ROWS][K][2]: the accumulation below is then plain two-wide vector math and compiles to v_pk_fma_f32
+  // on whole register pairs.  With single values in LDS the compiler picked v_pk_fma_f32 ... op_sel:[0,1,0] (the HIGH half of a
+  // loaded pair broadcast to both results) for every odd k, and that instruction form returned wrong sums in lanes 48..63
+  // whenever ANOTHER PROCESS ran MFMA kernels on the same GPU (two ranks sharing one device; never inside one process): minimal
+  // reproduction with the instruction forms side by side in scripts/probes/pkfma_probe.hip, log profiles/r03_pkfma_cross_process.txt
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2* as = reinterpret_cast<f32x2*>(smem_raw);
   const int b = blockIdx.y;
   const int fill = regs ? row_off : 0;             // leading register rows written by this launch
   const int rr0 = blockIdx.x * ROWS;               // row index within [0, fill + T)
   for (int i = threadIdx.x; i < ROWS * K; i += blockDim.x) {
     const int t = rr0 + i / K - fill;
-    as[i] = (t >= 0 && t < T) ? a[((int64_t)b * T + t) * K + (i % K)] : 0.f;
+    const float v = (t >= 0 && t < T) ? a[((int64_t)b * T + t) * K + (i % K)] : 0.f;
+    as[i] = f32x2{v, v};
   }
   __syncthreads();
   for (int n = threadIdx.x * 4; n < d; n += blockDim.x * 4) {
-    f32x4 acc[ROWS];
+    f32x2 acc2[ROWS][2];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < ROWS; ++r) acc2[r][0] = acc2[r][1] = f32x2{0.f, 0.f};
 #pragma unroll 8
     for (int k = 0; k < K; ++k) {
       const f32x4 w = *reinterpret_cast<const f32x4*>(wt + (int64_t)k * d + n);
+      const f32x2 w0 = {w[0], w[1]}, w1 = {w[2], w[3]};
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
-        const float av = as[r * K + k];
-        acc[r][0] += av * w[0];
-        acc[r][1] += av * w[1];
-        acc[r][2] += av * w[2];
-        acc[r][3] += av * w[3];
+        const f32x2 aa = as[r * K + k];
+        acc2[r][0] += aa * w0;
+        acc2[r][1] += aa * w1;
       }
     }
+    f32x4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = f32x4{acc2[r][0][0], acc2[r][0][1], acc2[r][1][0], acc2[r][1][1]};
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
@@ -832,13 +841,13 @@ extern "C" int v2a_linear_small(const float* a, int64_t M, int32_t K, const floa
   const int64_t nb8 = (int64_t)((rows + 7) / 8) * (M / T);
   if (nb8 >= 512) {
     dim3 grid((unsigned)((rows + 7) / 8), (unsigned)(M / T)), block(256);
-    hipLaunchKernelGGL((linear_small_kernel<8>), grid, block, 8 * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
+    hipLaunchKernelGGL((linear_small_kernel<8>), grid, block, 2 * 8 * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
                        T, out, obs, row_off, d, dup, regs, (bf16_t*)out_bf16);
   // (4-row blocks -- 196 blocks, one round at one clip -- measured 27 us against 16.5 us for the 391 blocks of 2 rows: the block time is
   // the latency chain of its K weight-row loads, and more blocks per CU overlap more of it)
   } else {
     dim3 grid((unsigned)((rows + 1) / 2), (unsigned)(M / T)), block(256);
-    hipLaunchKernelGGL((linear_small_kernel<2>), grid, block, 2 * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
+    hipLaunchKernelGGL((linear_small_kernel<2>), grid, block, 2 * 2 * K * sizeof(float), (hipStream_t)stream, a, K, wt, bias, add,
                        T, out, obs, row_off, d, dup, regs, (bf16_t*)out_bf16);
   }
   return v2a_check_launch("v2a_linear_small");
