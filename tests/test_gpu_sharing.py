@@ -63,17 +63,31 @@ def _sampler(mode):
     return lambda: m.sample(torch.zeros(n, T, cfg.num_channels), y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, **kw).float().cpu()
 
 
+def _neighbours():
+    """the roll encoder upstream and the vocoder downstream of the sampler, one small call each"""
+    import v2a_amd
+    from v2a_amd.synth import random_encodec_decoder_state_dict, random_video2roll_state_dict, synthetic_piano_frames
+    vsd, x = random_video2roll_state_dict(1), synthetic_piano_frames(1, 2, seed=1)
+    engines = {m: v2a_amd.Video2RollEngine(vsd, "cuda:0", compute=m) for m in ("fp32", "bf16")}
+    dec = v2a_amd.EncodecDecoder(random_encodec_decoder_state_dict(1), "cuda:0")
+    emb = torch.randn(1, 128, 16, generator=torch.Generator().manual_seed(2))
+    out = {"video2roll[%s]" % m: (lambda e=e: e.encode_frames(x, 6).float().cpu()) for m, e in engines.items()}
+    out["vocoder"] = lambda: dec.decoder(emb).float().cpu()
+    return out
+
+
 def test_results_do_not_depend_on_a_neighbour_process(busy_neighbour):
     from v2a_amd import _lib as L
     runs = {"embed": _embed(L)}
     for mode in ("bf16", "bf16x3", "fp32"):
         runs["sample[%s]" % mode] = _sampler(mode)
+    runs.update(_neighbours())
     quiet = {k: f() for k, f in runs.items()}
     for k, f in runs.items():
         assert torch.equal(f(), quiet[k]), k           # reproducible on the quiet device to begin with
     busy_neighbour["start"]()
     bad = {}
     for k, f in runs.items():
-        n = 60 if k == "embed" else 6
+        n = 60 if k == "embed" else (6 if k.startswith("sample") else 12)
         bad[k] = sum(not torch.equal(f(), quiet[k]) for _ in range(n))
     assert not any(bad.values()), "results changed beside a busy neighbour process (runs that differ): %s" % bad
