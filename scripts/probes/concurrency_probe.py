@@ -36,9 +36,14 @@ from v2a_amd.synth import random_state_dict, synthetic_conditioning  # noqa: E40
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+full = len(sys.argv) > 3 and sys.argv[3] == "full"          # the shipped shape: depth 12, dims 1024 / 1280 / 512, one clip of 750 frames
 dev = torch.device("cuda:0")
-cfg = v2a_amd.DiTConfig(dim=256, dim_text=320, dim_frames=128, depth=4, heads=4, frames_heads=2, num_registers=8, num_channels=32, max_seq_len=512)
-T, NC, steps, n = 120, 12, 8, 5
+if full:
+    cfg = v2a_amd.DiTConfig()
+    T, NC, steps, n = 750, 16, 6, 1
+else:
+    cfg = v2a_amd.DiTConfig(dim=256, dim_text=320, dim_frames=128, depth=4, heads=4, frames_heads=2, num_registers=8, num_channels=32, max_seq_len=512)
+    T, NC, steps, n = 120, 12, 8, 5
 sd = random_state_dict(cfg, seed=0, device="cpu")
 tk = {k: v for k, v in cfg.to_dict().items() if k not in ("num_channels", "notes", "cond_proj_in", "dim_context", "kernel_size", "ff_mult")}
 y0, text, roll, ctx, cm = synthetic_conditioning(cfg, n, T, NC, seed=77, piano=True, device="cpu")
@@ -71,6 +76,7 @@ def trial(name, graph=True, tuning=None, **sw):
 
 
 trial("default")
-trial("no graph", graph=False)
-trial("single stream", multi_stream=False)
-trial("fold_norm off", fold_norm=False)
+if not full:
+    trial("no graph", graph=False)
+    trial("single stream", multi_stream=False)
+    trial("fold_norm off", fold_norm=False)
