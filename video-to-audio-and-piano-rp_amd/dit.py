@@ -821,7 +821,9 @@ class DiTEngine:
                 kb = p["ctx_kv"].data_ptr() + i * inner * es
                 vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
                 aw = p["ao_a"].stride(-2)
-                one_launch = (self.fuse_xattn and self.adc in (L.BF16, L.BF16_SPLIT) and r2 <= 2400 and p["nc"] <= 64 and D % 512 == 0
+                # one launch while its 64-token x one-head workgroups stay under ~2.75 per CU (three clips at the shipped dims: 624; four clips
+                # -- 832 -- are faster as two launches on larger tiles, profiles/r03_xattn_probe.txt)
+                one_launch = (self.fuse_xattn and self.adc in (L.BF16, L.BF16_SPLIT) and nctx * -(-N // 64) * A2.heads <= 704 and p["nc"] <= 64 and D % 512 == 0
                               and A2.gate_col == A2.inner and (self._fuse_rope or not self.rope_cross))
                 if one_launch:
                     rk = dict(rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0) if self.rope_cross else {}
