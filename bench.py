@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--shapes", action="store_true", help="print a per-GEMM-shape timing table to stderr")
     ap.add_argument("--no-batched", action="store_true", help="skip the supplementary 8-clips-per-GPU measurement (N=1 only)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=4, help="grid points of the bounded CPU sample (SURVEY 8d: steps=4)")
-    ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered four phases per K tile, 2 lock-step, 3 staggered two phases)")
+    ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered, 2 lock-step)")
     ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
     ap.add_argument("--gemm-force-tile", type=int, default=-1, help="v2a_set_tuning: one tile configuration for every bf16 GEMM (experiment)")
     ap.add_argument("--xcd-1x8", action="store_true", help="A/B: round-1 XCD tile order (column strips) instead of the per-shape rectangle grid")

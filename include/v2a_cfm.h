@@ -162,8 +162,7 @@ typedef struct v2a_tuning {
   int32_t gemm_force_tile;        /* -1 = by shape; 0..5 = one LDS-DMA tile shape for every bf16 x bf16 GEMM (0 128x256, 1 128x128, 2 128x64, 3 64x64, 5 256x256), 6 = the 256x256 8-phase kernel, 7 / 8 = 64x128 / 64x64 with a 6-deep ring */
   int32_t gemm_k_rotation;        /* ignored since ABI 5 (was: M bands that share a W panel start their K walk at different K tiles; +0.7 %, and it made
                                    * the fp32 summation order depend on M): the K loop now walks running pointers */
-  int32_t gemm_8phase;            /* 256x256 phase-interleaved kernel for wide outputs (N >= 2048): 0 off, 1 on (staggered wave rows, four phases per K tile),
-                                   * 2 on (lock-step), 3 on (staggered, two 32-MFMA phases per K tile: half the barriers; the default) */
+  int32_t gemm_8phase;            /* 256x256 phase-interleaved kernel for wide outputs (N >= 2048): 0 off, 1 on (staggered wave rows), 2 on (lock-step) */
   int32_t gemm_8phase_min_tiles;  /* ... when the problem yields at least this many 256x256 tiles (0 = 400) */
   int32_t dwconv_rows_per_wave;   /* v2a_dwconv_silu_residual: output positions per wave pass of the small-launch kernel, 4 or 6 (0 = default 4);
                                    * -1 = never use the streaming kernel that chip-filling launches take (A/B) */

@@ -13,7 +13,7 @@ import v2a_amd  # noqa: E402,F401
 from v2a_amd import _lib  # noqa: E402
 
 MODE = None
-if sys.argv[1].startswith("mode"):          # "mode1" / "mode2" / "mode3": the shipped library with v2a_tuning.gemm_8phase = 1 / 2 / 3
+if sys.argv[1].startswith("mode"):          # "mode1" / "mode2": the shipped library with v2a_tuning.gemm_8phase = 1 / 2
     MODE = int(sys.argv[1][4:])
 else:
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])

@@ -212,7 +212,7 @@ def test_gemm_big_tile_persistent_configs(L, M, N, K, epi):
         torch.testing.assert_close(out.cpu().double(), ref, atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("stagger", [1, 2, 3])
+@pytest.mark.parametrize("stagger", [1, 2])
 @pytest.mark.parametrize("M,N,ks,epi", [(1564, 3088, (1024,), "store_rope"), (1564, 8192, (1024,), "geglu"), (300, 512, (64,), "store"),
                                         (1564, 1024, (1024, 1280, 512), "resid"), (782, 1280, (128, 64), "gate_resid"),
                                         (2600, 768, (192,), "store_f32"), (257, 272, (320,), "resid")])

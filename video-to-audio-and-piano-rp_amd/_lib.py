@@ -168,7 +168,7 @@ def set_tuning(force_tile: int = -1, k_rotation: bool = False, eight_phase: int 
             and not xcd_order_1x8 and attn_one_group_from == 0):
         check(lib().v2a_set_tuning(None))
         return
-    t = Tuning(force_tile, 1 if k_rotation else 0, 3 if eight_phase is None else eight_phase, eight_phase_min_tiles, dwconv_rows_per_wave,
+    t = Tuning(force_tile, 1 if k_rotation else 0, 1 if eight_phase is None else eight_phase, eight_phase_min_tiles, dwconv_rows_per_wave,
                1 if xcd_order_1x8 else 0, attn_one_group_from)
     check(lib().v2a_set_tuning(C.byref(t)))
 

@@ -535,7 +535,7 @@ int dispatch_s3(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 // (A/B on MI355X: +1..2 % at 8 clips per GPU end to end).  At one clip its 224-280 workgroups of 128 KB LDS take every CU for
 // 35-70 us: alone it is the fastest choice for the feed-forward GEMMs (774 vs 644 TF/s), beside the other two streams of the
 // sampler it costs 1.3 % end to end, and with fewer tiles the 128x256 ring kernel fills the chip better anyway.
-static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 3, 400, 1, 0};
+static constexpr v2a_detail::GemmTuning kDefaultTuning = {-1, 0, 1, 400, 1, 0};
 v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 int v2a_detail::g_attn_one_group_from = 1536;
@@ -557,7 +557,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   V2A_REQUIRE(t->dwconv_rows_per_wave == 0 || t->dwconv_rows_per_wave == 4 || t->dwconv_rows_per_wave == 6 || t->dwconv_rows_per_wave == -1,
               "v2a_set_tuning: dwconv_rows_per_wave %d", t->dwconv_rows_per_wave);
   V2A_REQUIRE(t->gemm_force_tile >= -1 && t->gemm_force_tile <= 8 && t->gemm_force_tile != 4, "v2a_set_tuning: gemm_force_tile %d", t->gemm_force_tile);
-  V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 3, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
+  V2A_REQUIRE(t->gemm_8phase >= 0 && t->gemm_8phase <= 2, "v2a_set_tuning: gemm_8phase %d", t->gemm_8phase);
   V2A_REQUIRE(t->gemm_8phase_min_tiles >= 0 && t->attn_one_group_from >= 0, "v2a_set_tuning: negative threshold");
   v2a_detail::g_dwconv_rows_per_wave = t->dwconv_rows_per_wave > 0 ? t->dwconv_rows_per_wave : 4;
   v2a_detail::g_dwconv_stream = t->dwconv_rows_per_wave == -1 ? 0 : 1;

@@ -34,12 +34,13 @@ constexpr int kSkip = V2A_8PH_SKIP;
 constexpr int kSkip = 0;
 #endif
 
-// MODE: 1 = four phases per K tile, wave rows staggered; 2 = four phases, lock-step; 3 = TWO phases per K tile (32 MFMAs between
-// barriers: {A0, B0, B1 reads + AH1(t+1) DMA | quadrants (0,0) (0,1)}, {A1 reads + AH0 / BH0 / BH1 (t+2) DMAs, vmcnt(6) | (1,1) (1,0)}),
-// staggered: half the barriers for the same registers (A1 still lands on A0's registers, both B sub-tiles live through the K tile)
+// MODE: 1 = wave rows staggered, 2 = lock-step.  (A variant with TWO phases per K tile -- 32 MFMAs between barriers, the same registers --
+// was 2-3 % faster per launch only while its DMAs were issued in the read blocks, where the wave row that runs one barrier behind may
+// still have fragment reads of the restaged half tile in flight: safe by timing, not by a barrier.  Issued behind the barriers that make
+// it safe by construction it was 10-15 % slower than four phases: profiles/r03_8phase_two_phase_mode.txt.  Four phases stay.)
 template <int EPI, typename OutT, int MODE>
 __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
-  constexpr bool STAGGER = MODE != 2, LONG = MODE == 3;
+  constexpr bool STAGGER = MODE != 2;
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, TM = 8, TN = 4;
   constexpr int HALF = 128 * 128;               // bytes of a half tile
   constexpr int BUF = 4 * HALF;                 // AH0 | AH1 | BH0 | BH1
@@ -218,44 +219,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
-  auto ktile2 = [&](auto buf_c, int t) {
-    constexpr int B = decltype(buf_c)::value;
-    // phase A: AH1 of the other buffer was last read in phase B of K tile t-1
-    read_a(0, B);
-    read_b(0, B, bf0);
-    read_b(1, B, bf1);
-    if (t + 1 < nk) stage_a(1, t + 1, B ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    quadrant(I0{}, I0{}, bf0);
-    quadrant(I0{}, I1{}, bf1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase B: AH0 / BH0 / BH1 of this buffer were last read in phase A; K tile t+1 (last piece: AH1 from phase A) must have landed
-    read_a(1, B);
-    if (t + 2 < nk) {
-      stage_a(0, t + 2, B);
-      stage_b(0, t + 2, B);
-      stage_b(1, t + 2, B);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    quadrant(I1{}, I1{}, bf1);
-    quadrant(I1{}, I0{}, bf0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-  };
   for (int t = 0; t < nk; t += 2) {
-    if constexpr (LONG) {
-      ktile2(I0{}, t);
-      if (t + 1 < nk) ktile2(I1{}, t + 1);
-    } else {
-      ktile(I0{}, t);
-      if (t + 1 < nk) ktile(I1{}, t + 1);
-    }
+    ktile(I0{}, t);
+    if (t + 1 < nk) ktile(I1{}, t + 1);
   }
   if constexpr (STAGGER) {
     if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two wave rows: everyone is out of the K loop after this
@@ -286,7 +252,6 @@ int launch_8ph(const GemmParams& p_in, hipStream_t s) {
   };
   int rc;
   if (mode == 2) rc = go(gemm_bf16_8ph_kernel<EPI, OutT, 2>);
-  else if (mode == 3) rc = go(gemm_bf16_8ph_kernel<EPI, OutT, 3>);
   else rc = go(gemm_bf16_8ph_kernel<EPI, OutT, 1>);
   if (rc) return rc;
   return v2a_check_launch("v2a_gemm(8-phase)");

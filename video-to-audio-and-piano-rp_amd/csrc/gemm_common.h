@@ -72,7 +72,7 @@ struct GemmParams {
 struct GemmTuning {
   int force_tile;        // -1 = by shape
   int krot;              // K rotation (see gemm_bf16_dma_kernel)
-  int use_8phase;        // 256x256 phase-interleaved kernel for wide outputs: 0 off, 1 staggered wave rows (4 phases per K tile), 2 lock-step, 3 staggered with 2 long phases per K tile (default)
+  int use_8phase;        // 256x256 phase-interleaved kernel for wide outputs: 0 off, 1 staggered wave rows, 2 lock-step
   int min_tiles_8phase;  // ... when the problem has at least this many 256x256 tiles
   int xcd_grid;          // 1: XCD rectangle grid chosen per shape, 0: always 1 x 8 (every XCD walks all M of its column strip)
   int dbg;               // probe builds only: v2a_tuning.reserved[0]
