@@ -51,7 +51,7 @@ enum {
   V2A_ERR_LAUNCH = -2  /* hipGetLastError() after launch */
 };
 
-int v2a_abi_version(void);        /* 6 */
+int v2a_abi_version(void);        /* 7 */
 const char* v2a_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -307,7 +307,10 @@ int v2a_time_cond(const float* t, int32_t S, const float* fourier_w, const float
  * torchdiffeq Euler step (x3:2255).
  * ------------------------------------------------------------------------------------- */
 int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t T, int32_t C,
-                   int64_t pred_batch_stride, int32_t row_off, v2a_stream_t stream);
+                   int64_t pred_batch_stride, int32_t row_off,
+                   const int32_t* valid_rows /* ABI 7: device int or NULL (= T): only rows [0, valid_rows[0]) of every clip enter the sums --
+                                                the frames of the call, when the plan's T is padded to a shape bucket */,
+                   v2a_stream_t stream);
 int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C,
                   int64_t pred_batch_stride, int32_t row_off, float cfg_strength,
                   const float* dt, const int32_t* step, const double* apg,

@@ -67,7 +67,7 @@ def main():
     fw["t"] = np.float32(0.37)
     np.savez_compressed(os.path.join(OUT, "forward_small.npz"), **fw)
 
-    # 2. 4-step CFG samples: full length, ragged durations, video_drop_prompt, APG branch, no rope in cross-attn
+    # 2. 4-step CFG samples: full length, ragged durations, video_drop_prompt, APG branch, the other A7 reading (rope in cross-attention)
     sm = dict(common)
     kw = dict(steps=4, cfg_strength=2.0, sway_sampling=True)
     with torch.no_grad():
@@ -78,8 +78,8 @@ def main():
         sm["y_dropprompt"] = O.sample(P, cfg, y0, text, roll, ctx, cm, remove_parallel_component=False,
                                       video_drop_prompt=[False, True], **kw).numpy()
         sm["y_apg"] = O.sample(P, cfg, y0, text, roll, ctx, cm, remove_parallel_component=True, **kw).numpy()
-        sm["y_norope_cross"] = O.sample(P, cfg, y0, text, roll, ctx, cm, remove_parallel_component=False,
-                                        opts=O.OracleOptions(rope_cross=False), **kw).numpy()
+        sm["y_rope_cross"] = O.sample(P, cfg, y0, text, roll, ctx, cm, remove_parallel_component=False,
+                                      opts=O.OracleOptions(rope_cross=True), **kw).numpy()
         sm["y_steps8_nosway"] = O.sample(P, cfg, y0, text, roll, ctx, cm, steps=8, cfg_strength=3.0,
                                          sway_sampling=False, remove_parallel_component=False).numpy()
     sm["ragged_duration"] = np.array([T, 29])
@@ -108,6 +108,8 @@ def main():
         blk["ctx"], blk["ctx_mask"] = ctxb.numpy(), cmb.numpy()
         blk["cross_attn"] = O.attention(P, f"{L0}.0.6", x, cfg.heads, 64, freqs, mask, O.OracleOptions(),
                                         context=ctxb, context_mask=cmb).numpy()
+        blk["cross_attn_rope"] = O.attention(P, f"{L0}.0.6", x, cfg.heads, 64, freqs, mask, O.OracleOptions(rope_cross=True),
+                                             context=ctxb, context_mask=cmb).numpy()
         blk["feedforward"] = O.feedforward(P, f"{L0}.0.9", x).numpy()
         tx = torch.randn(2, 44, 192, generator=g)
         fr = torch.randn(2, 44, 64, generator=g)

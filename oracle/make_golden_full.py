@@ -9,9 +9,13 @@ BASELINE.json configs[1] inputs (depth 12, dim 1024/1280/512, T = 750, nc = 16, 
   y_steps4_piano      the same with the V2P roll (`piano=True`, configs[3])    (750, 128)
   y_steps32           32-point sway grid, CFG 2.0 (configs[1])                 (750, 128)
   traj32_sub          every grid point of that run on every 8th latent frame   (32, 94, 128)
+  y_steps64_piano     configs[3] at its real size: V2P roll on the 64-point grid of src/inference_v2p.py:183   (750, 128)
+  y_steps4_ropecross, y_steps32_ropecross, traj32_sub_ropecross
+                      the other reading of A7 (`OracleOptions(rope_cross=True)`: rotary applied in cross-attention);
+                      the vectors above use the default reading (x-transformers 1.37.4 ignores it, oracle header)
 
 Like every fixture of this path these pin the ORACLE (parity of the sampler stays "unpinned": the reference holds
-no vectors and cannot be imported).  About 75 full-size forwards: ~8 min on 8 cores.
+no vectors and cannot be imported).  About 270 full-size forwards: ~30 min on 8 cores.
 
 Usage:  python oracle/make_golden_full.py        (writes tests/golden/sample_full.npz)
 """
@@ -54,7 +58,15 @@ def main():
         out["y_steps32"] = y[0].numpy()
         out["traj32_sub"] = torch.stack([p[0, ::SUB] for p in traj]).numpy()
         print("steps32 done %.0f s" % (time.time() - t0), flush=True)
-    out["meta"] = json.dumps(dict(param_seed=0, input_seed=0, T=750, nc=16, cfg_strength=2.0, traj_frame_stride=SUB,
+        rc = O.OracleOptions(rope_cross=True)
+        out["y_steps4_ropecross"] = O.sample(P, cfg, y0, text, roll, ctx, cm, steps=4, opts=rc, **kw)[0].numpy()
+        y, traj = O.sample(P, cfg, y0, text, roll, ctx, cm, steps=32, return_trajectory=True, opts=rc, **kw)
+        out["y_steps32_ropecross"] = y[0].numpy()
+        out["traj32_sub_ropecross"] = torch.stack([p[0, ::SUB] for p in traj]).numpy()
+        print("steps4 + steps32 with rope in cross-attention done %.0f s" % (time.time() - t0), flush=True)
+        out["y_steps64_piano"] = O.sample(P, cfg, y0p, textp, rollp, ctxp, cmp_, steps=64, **kw)[0].numpy()
+        print("steps64 piano done %.0f s" % (time.time() - t0), flush=True)
+    out["meta"] = json.dumps(dict(param_seed=0, input_seed=0, T=750, nc=16, cfg_strength=2.0, traj_frame_stride=SUB, rope_cross_default=O.OracleOptions().rope_cross,
                                   torch=torch.__version__))
     np.savez_compressed(os.path.join(OUT, "sample_full.npz"), **out)
     print("wrote sample_full.npz", {k: getattr(v, "shape", None) for k, v in out.items()})

@@ -17,6 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--load":
     a = torch.randn(2048, 2048, device="cuda", dtype=torch.bfloat16)
     big = torch.empty(64 << 20, device="cuda")
     t_end = time.time() + float(sys.argv[2])
+    ready = sys.argv[4] if len(sys.argv) > 4 else None         # file written once the first matmuls have completed on the device
     while time.time() < t_end:
         if kind == "idle":
             time.sleep(0.1)
@@ -27,6 +28,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--load":
             if kind in ("both", "fill"):
                 big.fill_(1.0)
         torch.cuda.synchronize()
+        if ready:
+            open(ready, "w").write("ready\n")
+            ready = None
     sys.exit(0)
 
 import torch  # noqa: E402

@@ -42,3 +42,26 @@ def test_bench_help_lists_the_contract_flags():
     assert out.returncode == 0, out.stderr[-500:]
     for flag in ("--gpus", "--steps", "--warmup", "--dtype", "--clips-per-gpu", "--no-cpu-baseline"):
         assert flag in out.stdout, flag
+
+
+def test_scaling_reference_field(bench):
+    """An N-GPU line carries the N = 1 comparator at the SAME per-GPU shape and the efficiency against it (the --gpus 1 default is one
+    clip, an N > 1 run 8 clips per GPU: a ratio of the two `value`s is not a scaling number)."""
+    r = bench.scaling_reference(8, 8800.0, 8 * 8800.0 * 0.9, 8)
+    assert r["clips_per_gpu"] == 8 and r["n1_same_shape_mel_frames_per_s"] == 8800.0 and abs(r["efficiency"] - 0.9) < 1e-4
+
+
+def test_summary_fields_pick_the_parity_qualified_mode(bench):
+    mk = lambda v, e, ok: {"mel_frames_per_s": v, "ms_per_step": 750e3 / v, "steps": 20, "warmup": 5, "max_abs_delta_mel": e,
+                           "max_abs_delta_mel_over_grid": e, "meets_1e-3": ok}
+    res = {"dtype": "bf16", "parity_mode": {"fp32": mk(987.0, 9e-6, True), "bf16x3": mk(2799.0, 9e-5, True), "bf16": mk(5757.0, 0.049, False)},
+           "batched": {"mel_frames_per_s": 8847.0, "ms_per_step": 678.2,
+                       "roofline": {"all_gemm_frac": 0.309, "kernels": {"gemm<bf16,a_bf16,geglu,bf16,8ph>": {"tflops": 947.0, "share": 0.3},
+                                                                         "gemm<bf16,a_bf16,store,bf16,8ph>": {"tflops": 585.0, "share": 0.1}}}},
+           "roofline": {"hbm": {"clips_8": {"rmsnorm": {"frac": 0.495}}}}}
+    out = bench.summary_fields(res)
+    pq = out["parity_qualified"]
+    assert pq["mode"] == "bf16x3" and pq["mel_frames_per_s"] == 2799.0 and pq["max_abs_delta_mel_over_grid"] < 1e-3 and "OUTSIDE" in pq["note"]
+    assert out["n1_8clips_mel_frames_per_s"] == 8847.0
+    assert list(out)[-1] == "summary" and out["summary"]["batched_8clips"]["frac_geglu"] == round(947.0 / 2500.0, 4)
+    assert res["roofline"]["clips8_frac_qkv_store_bf16"] == round(585.0 / 2500.0, 4) and out["summary"]["hbm_clips_8"] == {"rmsnorm": 0.495}

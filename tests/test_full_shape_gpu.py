@@ -6,7 +6,10 @@ committed oracle vectors tests/golden/sample_full.npz (oracle/make_golden_full.p
               same grid in the benchmarked bf16 mode (reported)   test_full_sample_steps32_bf16_report
   configs[2]  8 clips per GPU, clip 3 == the B=1 vector           test_config2_eight_clips_per_gpu (steps=4, fp32 + bf16)
               ... on the full 32-point grid, bf16x3 < 1e-3        test_config2_eight_clips_per_gpu_32_steps
-  configs[3]  V2P roll, steps=4 vs golden + 64-step run           test_config3_v2p_roll_and_64_steps
+  configs[3]  V2P roll, steps=4 vs golden + the 64-point grid of src/inference_v2p.py:183 vs `y_steps64_piano`
+              (fp32 and bf16x3 < 1e-3, bf16 reported)              test_config3_v2p_roll_and_64_steps
+  A7          the other reading (`rope_cross=True`, rotary in cross-attention): 4 and 32 points, fp32 and bf16x3 < 1e-3
+                                                                  test_full_sample_rope_cross_reading
   configs[4]  3 cascaded passes x 4 clips == independent calls    test_config4_cascade_equals_independent_calls
 
 The tolerance for fp32 mode is north_star's |delta mel| < 1e-3; bf16 numbers are printed and bounded at ~1.5x what the mode measures today."""
@@ -184,7 +187,8 @@ def test_config2_eight_clips_per_gpu_32_steps(full, mbf):
 
 def test_config3_v2p_roll_and_64_steps(full, m32, mbf):
     """configs[3]: non-zero piano roll (`piano=True`).  fp32 vs the golden vector at steps=4; then the CLI's 64-point grid
-    (src/inference_v2p.py:183) in the benchmarked mode: the device step counter must reach 63 and the latents stay finite."""
+    (src/inference_v2p.py:183; 63 CFG evaluations) against the oracle's `y_steps64_piano`: fp32 and bf16x3 inside north_star's 1e-3,
+    the benchmarked bf16 mode reported and bounded; the device step counter must reach 63."""
     f = full
     y0, text, roll, ctx, cm = O.synthetic_inputs(f["cfg"], 1, 750, nc=16, seed=0, piano=True)
     assert float(roll.abs().sum()) > 0
@@ -194,10 +198,38 @@ def test_config3_v2p_roll_and_64_steps(full, m32, mbf):
     assert float((f["g"]["y_steps4_piano"] - f["g"]["y_steps4"]).abs().max()) > 1e-2      # the roll really conditions the result
     print(f"configs[3] fp32 4-step V2P sample: max |delta mel| = {err:.3e}")
     assert err < 1e-3
+    want = f["g"]["y_steps64_piano"]
+    e32 = float((_sample(m32, f, 64, **kw)[0] - want).abs().max())
+    mx = make_model(f["cfg"], f["P"], "bf16x3")
+    ex3 = float((_sample(mx, f, 64, **kw)[0] - want).abs().max())
+    del mx
     out = _sample(mbf, f, 64, **kw)
     step = int(mbf.engine().plan["step"].item())
-    print(f"configs[3] bf16 64-step V2P sample: step counter {step}, |y| max {float(out.abs().max()):.2f}")
-    assert step == 63 and bool(torch.isfinite(out).all())
+    eb = (out[0] - want).abs()
+    print(f"configs[3] 64-point V2P sample vs oracle: fp32 {e32:.3e}, bf16x3 {ex3:.3e}, bf16 max {float(eb.max()):.4f} mean {float(eb.mean()):.5f}; "
+          f"step counter {step}")
+    assert e32 < 1e-3 and ex3 < 1e-3
+    assert step == 63 and bool(torch.isfinite(out).all()) and float(eb.max()) < 0.12 and float(eb.mean()) < 0.02
+
+
+def test_full_sample_rope_cross_reading(full):
+    """The other reading of A7 (`rope_cross=True`: x-transformers applying rotary_pos_emb in cross-attention as the call site x3:1131
+    asks; the default follows 1.37.4's `not has_context` guard): 4- and 32-point grids against the oracle vectors of THAT reading,
+    every grid point, fp32 and bf16x3 inside 1e-3 -- whichever reading a diff against the real package confirms, it is fixtured."""
+    f = full
+    g = f["g"]
+    assert float((g["y_steps32_ropecross"] - g["y_steps32"]).abs().max()) > 1e-2          # the switch really changes the result
+    for mode in ("fp32", "bf16x3"):
+        m = make_model(f["cfg"], f["P"], mode, rope_cross=True)
+        e4 = float((_sample(m, f, 4)[0] - g["y_steps4_ropecross"]).abs().max())
+        traj = []
+        got = _sample(m, f, 32, trajectory_out=traj)
+        sub = torch.stack([t[0, ::8].cpu() for t in traj])
+        per_point = float((sub - g["traj32_sub_ropecross"]).abs().amax(dim=(1, 2)).max())
+        err = float((got[0] - g["y_steps32_ropecross"]).abs().max())
+        print(f"A7 rope_cross=True {mode}: 4-point {e4:.3e}, 32-point final {err:.3e}, per grid point max {per_point:.3e}")
+        assert e4 < 1e-3 and err < 1e-3 and per_point < 1e-3
+        del m
 
 
 def test_config4_cascade_equals_independent_calls(full, mbf):

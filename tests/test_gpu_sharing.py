@@ -25,11 +25,21 @@ def busy_neighbour():
 
     def start():
         if child["p"] is None:
-            child["p"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "probes", "concurrency_probe.py"), "--load", "90", "matmul"],
+            import tempfile
+            ready = os.path.join(tempfile.mkdtemp(prefix="v2a_neighbour_"), "ready")
+            child["p"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "scripts", "probes", "concurrency_probe.py"), "--load", "240", "matmul", ready],
                                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            time.sleep(6.0)              # its first import of torch and the first matmuls
-            assert child["p"].poll() is None, "the neighbour process died"
+            # the neighbour writes the file after its first synchronised batch of matmuls (import of torch on a fresh box: up to minutes)
+            t_end = time.time() + 200.0
+            while not os.path.exists(ready):
+                assert child["p"].poll() is None, "the neighbour process died before its first matmul"
+                assert time.time() < t_end, "the neighbour process never reported its first matmul"
+                time.sleep(0.2)
+
+    def alive():
+        return child["p"] is not None and child["p"].poll() is None
     yield_box["start"] = start
+    yield_box["alive"] = alive
     yield yield_box
     if child["p"] is not None:
         child["p"].kill()
@@ -90,4 +100,5 @@ def test_results_do_not_depend_on_a_neighbour_process(busy_neighbour):
     for k, f in runs.items():
         n = 60 if k == "embed" else (6 if k.startswith("sample") else 12)
         bad[k] = sum(not torch.equal(f(), quiet[k]) for _ in range(n))
+    assert busy_neighbour["alive"](), "the neighbour process exited before the busy half was over: the comparison would be vacuous"
     assert not any(bad.values()), "results changed beside a busy neighbour process (runs that differ): %s" % bad

@@ -522,20 +522,23 @@ def test_attention_golden_self_and_cross(L, small, golden):
     N, d, H = 44, 128, 2
     lens = torch.tensor([44, 30], dtype=torch.int32, device=DEV)
     tab = _rope_table(N).to(DEV)
-    for name, cross in (("self_attn", False), ("cross_attn", True)):
+    for name, cross in (("self_attn", False), ("cross_attn", True), ("cross_attn_rope", True)):
+        rope = name != "cross_attn"          # A7: the default reading applies no rotary embedding in cross-attention
         pre = "transformer.layers.0.0.6" if cross else "transformer.layers.0.0.3"
         A = _Attn(P, pre, d, H, 64, torch.float32, DEV, cross=cross)
         xd = x.reshape(-1, d).to(DEV)
         qkv = torch.empty(2 * N, A.n_pad, device=DEV)
         L.gemm([(xd, d, d)], A.w_in, qkv, M=2 * N, N=A.n_pad, compute=L.F32, bias=A.b_in)
-        L.rope(qkv, rows=2 * N, row_stride=A.n_pad, nheads=(1 if cross else 2) * H, rows_per_batch=N, pos_offset=0, table=tab, layout=0)
+        if rope:
+            L.rope(qkv, rows=2 * N, row_stride=A.n_pad, nheads=(1 if cross else 2) * H, rows_per_batch=N, pos_offset=0, table=tab, layout=0)
         ao = torch.empty(2 * N, 128, device=DEV)
         if cross:
             ctx = torch.from_numpy(b["ctx"]).reshape(-1, d).to(DEV)
             wkv = torch.cat([P[f"{pre}.to_k.weight"], P[f"{pre}.to_v.weight"]], 0).to(DEV)
             kv = torch.empty(10, 256, device=DEV)
             L.gemm([(ctx, d, d)], wkv, kv, M=10, N=256, compute=L.F32)
-            L.rope(kv, rows=10, row_stride=256, nheads=H, rows_per_batch=5, pos_offset=N - 5, table=tab, layout=0)
+            if rope:
+                L.rope(kv, rows=10, row_stride=256, nheads=H, rows_per_batch=5, pos_offset=N - 5, table=tab, layout=0)
             L.attention(qkv.data_ptr(), kv.data_ptr(), kv.data_ptr() + 128 * 4, qkv.data_ptr() + A.gate_col * 4, ao.data_ptr(),
                         strides=(A.n_pad, 256, 256, A.n_pad, 128, N * A.n_pad, 5 * 256, 5 * 256, N * A.n_pad, N * 128),
                         B=2, H=H, Nq=N, Nk=5, kv_len=torch.tensor([5, 3], dtype=torch.int32, device=DEV), q_len=lens,
@@ -1076,10 +1079,10 @@ def test_qproj_xattn_equals_two_launches(L, B, Nq, Nk, kv_len, q_len, H, K, clam
 @pytest.mark.parametrize("B,Nq,Nk,kv_len,q_len", [(1, 782, 16, [11], [782]), (2, 782, 32, [32, 1], [782, 500]), (3, 100, 64, [64, 33, 0], [100, 64, 1])])
 @pytest.mark.parametrize("clamp", [50.0, 80.0, 0.0])
 @pytest.mark.parametrize("folded,rope", [(True, True), (False, False)])
-def test_qproj_xattn_split_equals_two_launches(L, B, Nq, Nk, kv_len, q_len, clamp, folded, rope):
+def test_qproj_xattn_split_equals_two_launches(L, B, Nq, Nk, kv_len, q_len, clamp, folded, rope, K=1024):
     """bf16x3 arithmetic: v2a_qproj_xattn on split operands == the split GEMM into an fp32 [q | gate] buffer followed by v2a_attention
     (dtype V2A_BF16_SPLIT, out_split), bit for bit -- and within 2e-4 of the fp32 reference."""
-    H, K = 16, 1024
+    H = 16
     g = _g(7 * B * Nq + Nk)
     M, inner, N = B * Nq, H * 64, H * 64 + 16
     a32 = torch.randn(M, K, generator=g) * 0.7
@@ -1110,6 +1113,13 @@ def test_qproj_xattn_split_equals_two_launches(L, B, Nq, Nk, kv_len, q_len, clam
     torch.cuda.synchronize()
     assert torch.isfinite(ref.float()).all() and ref.float().abs().max() > 0.05
     assert torch.equal(got, ref), (got.float() - ref.float()).abs().max()
+
+
+def test_qproj_xattn_split_small_k_then_large_k(L):
+    """The launch sizes its dynamic LDS by K (the preloaded gate row); the > 64 KB opt-in is set once per kernel for the largest K the
+    entry point takes, so a model of another width later in the process (K = 512, then K = 2048) is not refused."""
+    for K in (512, 2048):
+        test_qproj_xattn_split_equals_two_launches(L, 2, 782, 32, [32, 1], [782, 500], 50.0, True, True, K=K)
 
 
 def test_qproj_xattn_rejects_bad_args(L):

@@ -131,10 +131,12 @@ def test_audio_prompt_branch_vs_golden(small, mode, tol):
         assert err < tol, (name, err)
 
 
-def test_sample_half_layout_and_no_cross_rope(small, golden):
+def test_sample_half_layout_and_cross_rope(small, golden):
+    """The two switchable third-party readings: A6 half-split pair layout, and A7 rotary applied in cross-attention (`rope_cross=True`;
+    the default follows x-transformers 1.37.4, which ignores rotary_pos_emb when a context is given)."""
     i, g = small["inp"], golden["sample_small"]
     kw = dict(steps=4, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)
-    for name, mk in (("y_half_layout", dict(rope_layout="half")), ("y_norope_cross", dict(rope_cross=False))):
+    for name, mk in (("y_half_layout", dict(rope_layout="half")), ("y_rope_cross", dict(rope_cross=True))):
         m = make_model(small["cfg"], small["P"], "fp32", **mk)
         y = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
         assert np.abs(y.numpy() - g[name]).max() < TOL, name
@@ -366,6 +368,26 @@ def test_plan_cache_and_buckets(small, mode):
     assert len(exact.engine().plans) == 4 and exact.graph_captures == 5
     y = exact.sample(torch.zeros(2, 33, 16), y0=short["y0"], **_kw(short), **kw)
     assert torch.equal(y, outs["short"]) and exact.graph_captures == 5             # "short" was used after "long": still cached
+
+
+def test_buckets_with_remove_parallel_component(small):
+    """remove_parallel_component=True (the default of sample(), x3:2134): the projection's sums run over the call's own (b, n, C) frames
+    (x3:162-173).  A bucketed plan pads n behind them -- rows whose prediction is not zero -- so the reduction stops at the device-side
+    valid length: bucketed == exact plan, bit for bit in fp32, for two lengths that share one bucket and one captured graph."""
+    i = small["inp"]
+    kw = dict(cfg_strength=2.0, remove_parallel_component=True, return_raw_output=True, steps=4)
+    short = {k: v[:, :33] if k in ("y0", "text", "roll") else v for k, v in i.items()}
+    exact = make_model(small["cfg"], small["P"], "fp32")
+    buck = make_model(small["cfg"], small["P"], "fp32", bucket_frames=48)
+    for x, n in ((i, 40), (short, 33), (i, 40)):
+        a = exact.sample(torch.zeros(2, n, 16), y0=x["y0"], **_kw(x), **kw)
+        b = buck.sample(torch.zeros(2, n, 16), y0=x["y0"], **_kw(x), **kw)
+        assert torch.equal(a, b), (n, float((a - b).abs().max()))
+    assert buck.graph_captures == 1 and int(buck.engine().plan["valid_T"].item()) == 40
+    # a bucket that would run past the position table falls back to the exact shape instead of reading behind abs_pos_emb
+    tight = make_model(small["cfg"], small["P"], "fp32", bucket_frames=small["cfg"].max_seq_len + 44)
+    y = tight.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
+    assert tight.engine().plan["T"] == 40 and torch.equal(y, exact.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw))
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

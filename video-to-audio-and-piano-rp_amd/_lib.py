@@ -106,7 +106,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-ABI_VERSION = 6          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
+ABI_VERSION = 7          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
 
 
 def _declare(lib):
@@ -125,7 +125,7 @@ def _declare(lib):
     lib.v2a_linear_small.argtypes = [vp, i64, i32, vp, vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, vp]
     lib.v2a_fill_registers.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.v2a_time_cond.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp]
-    lib.v2a_apg_reduce.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp]
+    lib.v2a_apg_reduce.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp, vp]
     lib.v2a_cfg_euler.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, f32, vp]
     lib.v2a_step_advance.argtypes = [vp, vp]
     lib.v2a_cast_bf16.argtypes = [vp, vp, i64, vp]
@@ -447,8 +447,9 @@ def time_cond(t, fourier_w, wt, bias, out, *, S, d):
                               out.data_ptr(), d, stream_ptr()))
 
 
-def apg_reduce(pred, apg, *, B, T, C_, pred_batch_stride, row_off):
-    check(lib().v2a_apg_reduce(pred.data_ptr(), apg.data_ptr(), B, T, C_, pred_batch_stride, row_off, stream_ptr()))
+def apg_reduce(pred, apg, *, B, T, C_, pred_batch_stride, row_off, valid_rows=None):
+    """valid_rows: device int32[1] or None: the rows of every clip that enter the sums (a bucketed plan pads T behind them)."""
+    check(lib().v2a_apg_reduce(pred.data_ptr(), apg.data_ptr(), B, T, C_, pred_batch_stride, row_off, _p(valid_rows), stream_ptr()))
 
 
 def cfg_euler(y, pred, *, B, T, C_, pred_batch_stride, row_off, cfg_strength, dt, step=None, apg=None, keep=0.0):

@@ -7,7 +7,9 @@ BUILD=build
 if [ "$1" = "--probe" ]; then   # instrumented K loops for scripts/probes/kloop_probe.py: separate objects, separate library
   shift; OUT=../libv2a_cfm_probe.so; BUILD=build_probe; set -- -DV2A_GEMM_PROBE "$@"
 fi
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result $@"
+# -save-temps=obj: the gfx950 assembly of every object stays in $BUILD/<file>-hip-amdgcn-amd-amdhsa-gfx950.s -- tests/test_isa_guard.py reads
+# it (packed-FMA forms that must not come back, register spills); the other intermediates are removed below
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -save-temps=obj $@"
 mkdir -p $BUILD
 pids=()
 for f in gemm gemm_8phase rowops attention conv vocoder qproj_xattn; do
@@ -17,5 +19,6 @@ for f in gemm gemm_8phase rowops attention conv vocoder qproj_xattn; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
+rm -f $BUILD/*.hipi $BUILD/*.bc $BUILD/*.hipfb $BUILD/*.out $BUILD/*.resolution.txt $BUILD/*-host-*.s $BUILD/*-gfx950.o
 hipcc --offload-arch=gfx950 -shared -fPIC $BUILD/gemm.o $BUILD/gemm_8phase.o $BUILD/rowops.o $BUILD/attention.o $BUILD/conv.o $BUILD/vocoder.o $BUILD/qproj_xattn.o -o $OUT
 echo "built $(realpath $OUT)"

@@ -343,7 +343,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
 
   // epilogue operands are prefetched unless registers are short: the 256x256 tile (128 accumulators per lane) and the
   // 8-wave 128x256 tile with BOTH residual and gate rows (64 + 64 registers on top of two fragment sets)
-  constexpr bool PF = BM * BN <= 128 * 256 && !(EPI == V2A_EPI_GATE_RESID && BM * BN == 128 * 256);
+  // (round 4: the STORE epilogue's RoPE prefetch on that tile -- 64 more registers -- spilled 78 VGPRs to scratch, found by
+  // tests/test_isa_guard.py: off there too)
+  constexpr bool PF = BM * BN <= 128 * 256 && !((EPI == V2A_EPI_GATE_RESID || EPI == V2A_EPI_STORE) && BM * BN == 128 * 256);
   EpiPrefetch<EPI, TM, WN, PF> pf;
   if (p.vec_epi) pf.load(p, m0 + wm * WM, n0 + wn * WN, lane);
   // folded RMSNorm (consumer): the row's partial sums are requested ahead of the first operand DMA ...

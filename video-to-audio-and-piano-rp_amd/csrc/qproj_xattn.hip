@@ -479,9 +479,13 @@ __global__ __launch_bounds__(256) void qproj_xattn_kernel(QxParams P) {
 template <int CLAMP, bool S3>
 int launch_qx(const QxParams& P, hipStream_t s) {
   const size_t smem = 3 * (size_t)(64 + 64) * 128 * (S3 ? 2 : 1) + (size_t)P.g.K * 2 * (S3 ? 2 : 1) + 64 * 4;
+  // the dynamic LDS size depends on K (the preloaded gate row) while the opt-in above 64 KB is set ONCE per (kernel, device): it is set
+  // for the largest K the entry point accepts (4096), so a later launch with a larger K than the first one is not refused
+  constexpr size_t smem_max = 3 * (size_t)(64 + 64) * 128 * (S3 ? 2 : 1) + (size_t)4096 * 2 * (S3 ? 2 : 1) + 64 * 4;
+  static_assert(smem_max <= 160 * 1024, "qproj_xattn: LDS");
   auto kern = qproj_xattn_kernel<CLAMP, S3>;
   static std::atomic<uint64_t> lds_set{0};
-  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_qproj_xattn")) return rc;
+  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem_max, lds_set, "v2a_qproj_xattn")) return rc;
   hipLaunchKernelGGL(kern, dim3(P.nseq * P.tiles_per_seq * P.H), dim3(256), smem, s, P);
   return v2a_check_launch("v2a_qproj_xattn");
 }

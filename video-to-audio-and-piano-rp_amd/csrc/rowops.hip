@@ -9,7 +9,7 @@ namespace v2a_detail { extern int g_dwconv_rows_per_wave; extern int g_dwconv_st
 
 thread_local char v2a_err_buf[512] = {0};
 
-extern "C" int v2a_abi_version(void) { return 6; }
+extern "C" int v2a_abi_version(void) { return 7; }
 extern "C" const char* v2a_last_error(void) { return v2a_err_buf; }
 
 namespace {
@@ -618,10 +618,14 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ y, c
 }
 
 __global__ __launch_bounds__(256) void apg_reduce_kernel(const float* __restrict__ pred, double* __restrict__ apg, int B,
-                                                         int T, int C, int64_t pbs, int row_off) {
-  // grid = (chunks, B); fp64 partial sums, one atomic pair per block
+                                                         int T, int C, int64_t pbs, int row_off, const int32_t* __restrict__ valid_rows) {
+  // grid = (chunks, B); fp64 partial sums, one atomic pair per block.  valid_rows[0] (device side, so that ONE captured graph serves
+  // every length of a shape bucket) bounds the rows summed: the reference sums over the batch's own (b, n, C) tensor, x3:162-173 --
+  // rows a bucketed plan pads behind n are not part of it
   const int b = blockIdx.y;
-  const int64_t per_b = (int64_t)T * C;
+  int rows = T;
+  if (valid_rows) rows = min(T, max(0, valid_rows[0]));
+  const int64_t per_b = (int64_t)rows * C;
   double dot = 0.0, nn = 0.0;
   const float* pc = pred + (int64_t)b * pbs + (int64_t)row_off * C;
   const float* pn = pred + (int64_t)(b + B) * pbs + (int64_t)row_off * C;
@@ -872,7 +876,7 @@ extern "C" int v2a_time_cond(const float* t, int32_t S, const float* fw, const f
 }
 
 extern "C" int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t T, int32_t C, int64_t pbs,
-                              int32_t row_off, v2a_stream_t stream) {
+                              int32_t row_off, const int32_t* valid_rows, v2a_stream_t stream) {
   V2A_REQUIRE(pred && apg && B > 0 && T > 0 && C > 0, "v2a_apg_reduce: bad args");
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(apg, 0, sizeof(double) * 2 * B, s);
@@ -880,7 +884,7 @@ extern "C" int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t
   const int64_t per_b = (int64_t)T * C;
   int chunks = (int)((per_b + 256 * 8 - 1) / (256 * 8));
   if (chunks > 64) chunks = 64;
-  hipLaunchKernelGGL(apg_reduce_kernel, dim3(chunks, B), dim3(256), 0, s, pred, apg, B, T, C, pbs, row_off);
+  hipLaunchKernelGGL(apg_reduce_kernel, dim3(chunks, B), dim3(256), 0, s, pred, apg, B, T, C, pbs, row_off, valid_rows);
   return v2a_check_launch("v2a_apg_reduce");
 }
 

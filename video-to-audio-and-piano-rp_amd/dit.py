@@ -227,7 +227,7 @@ class DiTEngine:
     """One plan = fixed (Bt sequences, T frames, nc context tokens); all buffers preallocated."""
 
     def __init__(self, cfg: DiTConfig, state_dict: dict, device="cuda", compute: str = "bf16",
-                 rope_layout: str = "interleaved", rope_cross: bool = True,
+                 rope_layout: str = "interleaved", rope_cross: bool = False,
                  zero_masked_queries: bool = True, softclamp: float = 50.0, multi_stream: bool = True):
         assert compute in ("bf16", "fp32", "bf16x3")
         # "bf16x3": GEMM operands as bf16 hi | lo planes, three bf16 MFMA products per fp32 product (hi*hi + hi*lo + lo*hi);
@@ -302,6 +302,8 @@ class DiTEngine:
         c, dev, cd = self.cfg, self.dev, self.cd
         R = c.num_registers
         N = T + R
+        if T > c.max_seq_len:       # embed() indexes abs_pos_emb with the frame position (x3:957-960: the reference asserts the same)
+            raise ValueError(f"{T} latent frames exceed max_seq_len = {c.max_seq_len} of the position table")
         Bt = 2 * B if cfg_mode else B
         rows = Bt * N
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
@@ -351,6 +353,9 @@ class DiTEngine:
         p["dt"] = e(S)
         p["step"] = torch.zeros(1, dtype=torch.int32, device=dev)
         p["apg"] = torch.zeros(2 * B, dtype=torch.float64, device=dev)
+        # latent frames of the CALL (<= T when the plan is padded to a shape bucket): the APG sums of x3:162-173 run over the call's own
+        # (b, n, C) tensor, not over padding rows.  A device int -- a captured graph bakes scalar arguments, and one graph serves a bucket
+        p["valid_T"] = torch.full((1,), T, dtype=torch.int32, device=dev)
         p["seq_len"] = torch.full((Bt,), N, dtype=torch.int32, device=dev)
         p["ragged"] = False
         # rotary table (A6): cos/sin of pos * 10000^(-2i/64), computed like the oracle (CPU fp32)
@@ -582,6 +587,7 @@ class DiTEngine:
         B, Bt, T, N, nc, S = p["B"], p["Bt"], p["T"], p["N"], p["nc"], p["S"]
         R, D, Dt, Df = c.num_registers, c.dim, c.dim_text, c.dim_frames
         assert text.shape == (B, T, Dt) and frames_roll.shape == (B, T, c.notes) and context.shape == (B, nc, c.ctx_dim)
+        p["valid_T"].fill_(T if rope_len is None else min(T, int(rope_len) - R))
         # -- time conditioning + modulation tables for every grid point
         p["t_pts"].copy_(t_points.to(dev, torch.float32))
         if dt is not None:
@@ -897,7 +903,7 @@ class DiTEngine:
         kw = dict(B=p["B"], T=p["T"], C_=c.num_channels, pred_batch_stride=p["N"] * c.num_channels, row_off=c.num_registers)
         apg = None
         if remove_parallel_component:
-            L.apg_reduce(p["pred"], p["apg"], **kw)
+            L.apg_reduce(p["pred"], p["apg"], valid_rows=p["valid_T"], **kw)
             apg = p["apg"]
         L.cfg_euler(y, p["pred"], cfg_strength=cfg_strength, dt=p["dt"], step=p["step"], apg=apg, keep=keep_parallel_frac, **kw)
         L.step_advance(p["step"])

@@ -154,7 +154,7 @@ class E2TTS:
         compute_dtype: str = "bf16",         # "bf16" | "fp32" (parity mode, exact-fp32 MFMA) | "bf16x3" (parity-grade split-bf16 GEMMs)
         device="cuda",
         rope_layout: str = "interleaved",
-        rope_cross: bool = True,
+        rope_cross: bool = False,            # x-transformers 1.37.4 ignores rotary_pos_emb when a context is given; True = the other reading
         use_graph: bool = True,              # capture the Euler step in a hipGraph
         bucket_frames: int = 0,              # > 0: plans are padded to a multiple of this many latent frames (ragged masks hide the padding)
         bucket_ctx: int = 0,                 # > 0: ... and to a multiple of this many context tokens (context_mask hides the padding)
@@ -455,6 +455,8 @@ class E2TTS:
         #    keys stay those of the unpadded call (DiTEngine.prepare)
         nc = context.shape[1]
         n_plan = -(-n // self.bucket_frames) * self.bucket_frames if self.bucket_frames > 0 else n
+        if n_plan > cfgm.max_seq_len:       # the bucket would run past the position table: exact shape for this call
+            n_plan = n
         nc_plan = -(-nc // self.bucket_ctx) * self.bucket_ctx if self.bucket_ctx > 0 else nc
         pad_t = lambda x: x if x is None or x.shape[1] == n_plan else torch.nn.functional.pad(x, (0, 0, 0, n_plan - x.shape[1]))
         if nc_plan != nc:
