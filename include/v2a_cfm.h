@@ -152,6 +152,14 @@ typedef struct v2a_gemm_args {
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
+/* Grouped form (ABI 7): nprob (1..3) independent problems behind ONE kernel launch -- the same Linear of the audio, text and frames
+ * blocks of a layer (x3:1081-1137: A_i, T_i+1 and F_i+1 do not depend on each other), whose workgroups then share the chip inside one
+ * launch instead of three kernels queueing on three streams.  All problems bf16 x bf16 with dense rows and 16-byte aligned epilogue
+ * operands; one tile_hint for the group (0 = by shape); the epilogues of a group are either all STORE to bf16 (QKV projections, RoPE
+ * allowed), all GEGLU to bf16, or fp32 results with any mix of STORE / RESID / GATE_RESID (one kernel: an absent residual reads as 0,
+ * an absent gate as 1 -- bit-identical to the separate epilogues).  Problems are dispatched longest K first.  The result of every
+ * problem equals its own v2a_gemm call bit for bit (same K order per output element, same epilogue expressions). */
+int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_stream_t stream);
 /* sizeof(v2a_gemm_args) as the library was built: a binding checks its mirror of the struct against this */
 int v2a_gemm_args_size(void);
 
@@ -216,6 +224,21 @@ int v2a_dwconv_silu_residual_norm(const float* x, float* out, const float* wt, c
                                   int32_t B, int32_t N, int32_t d, int32_t ksize,
                                   const int32_t* len, const v2a_dwconv_norm* norm, v2a_stream_t stream);
 
+/* Grouped form (ABI 7): up to three convolutions -- the audio, text and frames blocks of one layer, x3:1082,1097,1122 -- as ONE launch
+ * while a single one cannot fill the chip (larger launches run one after another inside the call).  Same B, N, kernel size and length
+ * array; per problem its tensors, width and (all or none) the folded norm (`norm.out_bf16 == NULL`: none).  Results equal the separate
+ * calls bit for bit. */
+typedef struct v2a_dwconv_args {
+  const float* x;
+  float* out;
+  const float* wt;
+  const float* bias;
+  int32_t d, reserved;
+  v2a_dwconv_norm norm;
+} v2a_dwconv_args;
+int v2a_dwconv_grouped(const v2a_dwconv_args* args, int32_t nprob, int32_t B, int32_t N, int32_t ksize, const int32_t* len,
+                       v2a_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Rotary embedding applied in place to `nheads` consecutive 64-wide heads of every row
  * (the q and k column blocks of the fused QKV GEMM output).
@@ -254,6 +277,9 @@ typedef struct v2a_attn_args {
 } v2a_attn_args;
 
 int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);
+/* Grouped form (ABI 7): the bf16 self-attention of up to three blocks (audio / text / frames, x3:1084,1099,1126) as one launch over the
+ * heads of all problems; same B, Nq, Nk, scale, softclamp; per problem its tensors, strides, head count and length arrays. */
+int v2a_attention_grouped(const v2a_attn_args* args, int32_t nprob, v2a_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Cross-attention of the audio stream in ONE launch (ABI 6): the q-projection GEMM of v2a_gemm -- STORE epilogue with the optional

@@ -56,6 +56,12 @@ class DwconvNorm(C.Structure):
                 ("split", C.c_int32), ("reserved", C.c_int32)]
 
 
+class DwconvArgs(C.Structure):
+    """Mirror of `v2a_dwconv_args`: one problem of v2a_dwconv_grouped."""
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("wt", C.c_void_p), ("bias", C.c_void_p), ("d", C.c_int32), ("reserved", C.c_int32),
+                ("norm", DwconvNorm)]
+
+
 class Tuning(C.Structure):
     """Mirror of `v2a_tuning` (include/v2a_cfm.h): explicit tile-selection overrides, nothing is read from the environment."""
     _fields_ = [("gemm_force_tile", C.c_int32), ("gemm_k_rotation", C.c_int32), ("gemm_8phase", C.c_int32),
@@ -84,7 +90,7 @@ class RollHeadArgs(C.Structure):
 
 
 EXPORTS = [
-    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual", "v2a_dwconv_silu_residual_norm",
+    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_grouped", "v2a_attention_grouped", "v2a_dwconv_grouped", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual", "v2a_dwconv_silu_residual_norm",
     "v2a_rope_inplace", "v2a_attention", "v2a_qproj_xattn", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16", "v2a_split_bf16",
     "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
@@ -114,6 +120,9 @@ def _declare(lib):
     lib.v2a_abi_version.restype = C.c_int
     lib.v2a_last_error.restype = C.c_char_p
     lib.v2a_gemm.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.v2a_gemm_grouped.argtypes = [C.POINTER(GemmArgs), i32, vp]
+    lib.v2a_attention_grouped.argtypes = [C.POINTER(AttnArgs), i32, vp]
+    lib.v2a_dwconv_grouped.argtypes = [C.POINTER(DwconvArgs), i32, i32, i32, i32, vp, vp]
     lib.v2a_gemm_args_size.restype = C.c_int
     lib.v2a_set_tuning.argtypes = [C.POINTER(Tuning)]
     lib.v2a_attention.argtypes = [C.POINTER(AttnArgs), vp]
@@ -279,7 +288,27 @@ _EPI_NAMES = {0: "store", 1: "sigmoid", 2: "geglu", 3: "resid", 4: "gate_resid"}
 # thin typed wrappers (torch tensors are only carriers of device pointers here)
 # ------------------------------------------------------------------------------------------
 
-def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
+def gemm(a_segs, w, out, **kw):
+    """One v2a_gemm launch; arguments as for gemm_args."""
+    g, key, flops, nbytes = gemm_args(a_segs, w, out, **kw)
+    _launch(key, flops, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
+
+
+def gemm_grouped(built, tile_hint=0):
+    """built: 1..3 results of gemm_args -- independent problems run as ONE launch (v2a_gemm_grouped): the same Linear of the audio,
+    text and frames blocks of a layer.  tile_hint applies to the whole group (0 = by shape)."""
+    n = len(built)
+    arr = (GemmArgs * n)()
+    for i, (g, _, _, _) in enumerate(built):
+        C.memmove(C.byref(arr[i]), C.byref(g), C.sizeof(GemmArgs))
+        arr[i].tile_hint = tile_hint
+    epi = {b[0].epilogue for b in built}
+    key = "gemm_grouped<%s,%s%s>" % ("+".join(sorted(_EPI_NAMES[e] for e in epi)), "f32" if built[0][0].out_dtype == F32 else "bf16",
+                                     ",tile%d" % (tile_hint - 1) if tile_hint else "")
+    _launch(key, sum(b[2] for b in built), sum(b[3] for b in built), lambda: lib().v2a_gemm_grouped(arr, n, stream_ptr()))
+
+
+def gemm_args(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
          a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0,
@@ -341,7 +370,7 @@ def gemm(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=
         key = key[:-1] + ",tile%d>" % (g.tile_hint - 1)        # side-stream launches: tile shape chosen for running beside others
     if _prof is not None and _prof.shapes:
         key += " %dx%dx%d" % (M, N, K)
-    _launch(key, (6.0 if a_split else 2.0) * M * N * K, nbytes * (2 if a_split else 1), lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
+    return g, key, (6.0 if a_split else 2.0) * M * N * K, nbytes * (2 if a_split else 1)
 
 
 def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch_stride=0, rows_per_batch=0,
@@ -357,13 +386,7 @@ def rmsnorm(x, y, *, rows, d, gamma, step=None, gamma_step_stride=0, gamma_batch
                                       stream_ptr()))
 
 
-def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm=None):
-    """norm = dict(out_bf16, gamma, ssq, step=None, step_stride=0, batch_stride=0): the RMSNorm after the conv folded in."""
-    if norm is None:
-        _launch("dwconv", 2.0 * B * N * d * ksize, B * N * d * 8,
-                lambda: lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
-                                                       B, N, d, ksize, _p(lens), stream_ptr()))
-        return
+def _dwconv_norm(norm, d):
     n = DwconvNorm()
     n.out_bf16, n.ld_out_bf16 = norm["out_bf16"].data_ptr(), norm.get("ld_out_bf16", d)
     n.norm_gamma, n.step = norm["gamma"].data_ptr(), _p(norm.get("step"))
@@ -372,6 +395,32 @@ def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm=None):
     n.split = 1 if norm.get("split") else 0
     if n.split:
         n.ld_out_bf16 = norm.get("ld_out_bf16", 2 * d)
+    return n
+
+
+def dwconv_grouped(probs, *, B, N, ksize, lens=None):
+    """probs: 1..3 dicts(x, out, wt, bias, d, norm=None or the dict of dwconv()) -- the convolutions of the audio / text / frames blocks
+    of a layer as one launch (v2a_dwconv_grouped)."""
+    n = len(probs)
+    arr = (DwconvArgs * n)()
+    for i, q in enumerate(probs):
+        arr[i].x, arr[i].out, arr[i].wt, arr[i].bias, arr[i].d = q["x"].data_ptr(), q["out"].data_ptr(), q["wt"].data_ptr(), q["bias"].data_ptr(), q["d"]
+        if q.get("norm") is not None:
+            arr[i].norm = _dwconv_norm(q["norm"], q["d"])
+    dsum = sum(q["d"] for q in probs)
+    with_norm = probs[0].get("norm") is not None
+    _launch("dwconv_grouped+norm" if with_norm else "dwconv_grouped", 2.0 * B * N * dsum * ksize, B * N * dsum * (10 if with_norm else 8),
+            lambda: lib().v2a_dwconv_grouped(arr, n, B, N, ksize, _p(lens), stream_ptr()))
+
+
+def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm=None):
+    """norm = dict(out_bf16, gamma, ssq, step=None, step_stride=0, batch_stride=0): the RMSNorm after the conv folded in."""
+    if norm is None:
+        _launch("dwconv", 2.0 * B * N * d * ksize, B * N * d * 8,
+                lambda: lib().v2a_dwconv_silu_residual(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                                       B, N, d, ksize, _p(lens), stream_ptr()))
+        return
+    n = _dwconv_norm(norm, d)
     _launch("dwconv+norm", 2.0 * B * N * d * ksize, B * N * d * 10,
             lambda: lib().v2a_dwconv_silu_residual_norm(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
                                                         B, N, d, ksize, _p(lens), C.byref(n), stream_ptr()))
@@ -383,8 +432,22 @@ def rope(qk, *, rows, row_stride, nheads, rows_per_batch, pos_offset, table, lay
                                            pos_offset, table.data_ptr(), layout, stream_ptr()))
 
 
-def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype, out_split=False):
-    """q,k,v,gate,out: integer device addresses (views into fused buffers)."""
+def attention(q, k, v, gate, out, **kw):
+    """q,k,v,gate,out: integer device addresses (views into fused buffers); one v2a_attention launch."""
+    a, key, flops, nbytes = attention_args(q, k, v, gate, out, **kw)
+    _launch(key, flops, nbytes, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
+
+
+def attention_grouped(built):
+    """built: 1..3 results of attention_args (bf16, same B / Nq / Nk / scale / softclamp): one launch over the heads of all of them."""
+    n = len(built)
+    arr = (AttnArgs * n)()
+    for i, (a, _, _, _) in enumerate(built):
+        C.memmove(C.byref(arr[i]), C.byref(a), C.sizeof(AttnArgs))
+    _launch("attention_grouped<bf16>", sum(b[2] for b in built), sum(b[3] for b in built), lambda: lib().v2a_attention_grouped(arr, n, stream_ptr()))
+
+
+def attention_args(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype, out_split=False):
     a = AttnArgs()
     a.q, a.k, a.v, a.gate, a.out = q, k, v, gate, out
     (a.q_row_stride, a.k_row_stride, a.v_row_stride, a.gate_row_stride, a.out_row_stride,
@@ -394,8 +457,7 @@ def attention(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=N
     a.scale, a.softclamp, a.dtype = scale, softclamp, dtype
     a.out_split = 1 if out_split else 0
     esz = 2 if dtype == BF16 else 4
-    _launch("attention<%s>" % {BF16: "bf16", F32: "f32", BF16_SPLIT: "bf16x3"}[dtype], 4.0 * B * H * Nq * Nk * 64,
-            B * H * 64 * (2 * Nq + 2 * Nk) * esz, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
+    return a, "attention<%s>" % {BF16: "bf16", F32: "f32", BF16_SPLIT: "bf16x3"}[dtype], 4.0 * B * H * Nq * Nk * 64, B * H * 64 * (2 * Nq + 2 * Nk) * esz
 
 
 def qproj_xattn(a, lda, K, w, *, bias, M, N, rows_per_batch, k, v, out, kv_strides, out_strides, B, H, Nk, kv_len=None, q_len=None,

@@ -10,6 +10,7 @@
 //   * attn_mfma_kernel (bf16): flash-style, QK^T and PV on v_mfma_f32_16x16x32_bf16 with
 //     the softmax row reductions done by wavefront shuffles.
 #include "v2a_common.h"
+#include <type_traits>
 
 namespace v2a_detail { extern int g_attn_one_group_from; extern int g_probe_dbg; }
 
@@ -136,8 +137,28 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
 // logits are bounded by +-clamp, so with clamp * log2(e) <= 100 the weights 2^v lie in [2^-100, 2^100] and their sums over any
 // realistic key count stay far inside fp32 (and bf16 keeps fp32's exponent range for the P operand): the maximum, the
 // subtraction, the rescale of O and l per tile and two wave shuffles per tile disappear from a VALU-bound loop.
-template <int NG, int CLAMP>
-__global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
+// Grouped launch (v2a_attention_grouped): the self-attention of the audio, text and frames blocks of a layer as ONE launch -- blockIdx.y
+// runs over the heads of all problems (16 + 16 + 8), each head's workgroups take their problem's parameter block.  The problems share
+// B, Nq and the launch geometry; pointers, strides, head counts and lengths are per problem.
+constexpr int kAttnGroupMax = 3;
+struct AttnGroup {
+  int32_t nprob;
+  int32_t hstart[kAttnGroupMax + 1];
+  AttnParams p[kAttnGroupMax];
+};
+
+template <int NG, int CLAMP, bool GROUPED = false>
+__global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(const std::conditional_t<GROUPED, AttnGroup, AttnParams> arg) {
+  int h_ = blockIdx.y;
+  const AttnParams* pp_;
+  if constexpr (GROUPED) {
+    const int j = (h_ >= arg.hstart[1] ? 1 : 0) + (h_ >= arg.hstart[2] ? 1 : 0);
+    h_ -= arg.hstart[j];
+    pp_ = &arg.p[j];
+  } else {
+    pp_ = &arg;
+  }
+  const AttnParams& p = *pp_;
   constexpr int TK = 64;
   constexpr int K_ELEMS = TK * 64, V_ELEMS = TK * 64;     // both tiles row-major [key][64], 16-B chunks XOR-swizzled by (key & 7)
   constexpr int RING = 2 * (K_ELEMS + V_ELEMS);
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(AttnParams p) {
   bf16_t* lds = lds_all + grp * RING;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = h_, b = blockIdx.z;
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int query = q0 + lr;
   const int kvn = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;
@@ -995,4 +1016,52 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   }
   if (rc != V2A_OK) return rc;
   return v2a_check_launch("v2a_attention");
+}
+
+// The bf16 self-attention of up to three blocks in one launch (audio / text / frames streams of a layer): same B, Nq, Nk, scale and soft
+// clamp, per-problem tensors, strides, head counts and length arrays.  Same kernel, same arithmetic, same results as nprob v2a_attention calls.
+extern "C" int v2a_attention_grouped(const v2a_attn_args* args, int32_t nprob, v2a_stream_t stream) {
+  V2A_REQUIRE(args != nullptr && nprob >= 1 && nprob <= kAttnGroupMax, "v2a_attention_grouped: %d problems (1..%d)", nprob, kAttnGroupMax);
+  if (nprob == 1) return v2a_attention(args, stream);
+  AttnGroup g{};
+  g.nprob = nprob;
+  int htot = 0;
+  for (int j = 0; j < nprob; ++j) {
+    const v2a_attn_args* a = args + j;
+    V2A_REQUIRE(a->q && a->k && a->v && a->out && a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, "v2a_attention_grouped: problem %d: null tensor or empty shape", j);
+    V2A_REQUIRE(a->dtype == V2A_BF16 && !a->out_split, "v2a_attention_grouped: bf16 problems only (problem %d: dtype %d)", j, a->dtype);
+    V2A_REQUIRE(a->B == args[0].B && a->Nq == args[0].Nq && a->Nk == args[0].Nk && a->scale == args[0].scale && a->softclamp == args[0].softclamp,
+                "v2a_attention_grouped: problem %d differs from problem 0 in B / Nq / Nk / scale / softclamp", j);
+    const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) == 0 && ((uintptr_t)a->out & 7) == 0 &&
+                         a->q_row_stride % 8 == 0 && a->k_row_stride % 8 == 0 && a->v_row_stride % 8 == 0 &&
+                         a->q_batch_stride % 8 == 0 && a->k_batch_stride % 8 == 0 && a->v_batch_stride % 8 == 0 &&
+                         a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
+    V2A_REQUIRE(aligned, "v2a_attention_grouped: problem %d: head slices must be 16-byte aligned, output rows 8-byte aligned", j);
+    AttnParams& p = g.p[j];
+    p.q = a->q; p.k = a->k; p.v = a->v; p.gate = a->gate; p.out = a->out;
+    p.qrs = a->q_row_stride; p.krs = a->k_row_stride; p.vrs = a->v_row_stride; p.grs = a->gate_row_stride; p.ors = a->out_row_stride;
+    p.qbs = a->q_batch_stride; p.kbs = a->k_batch_stride; p.vbs = a->v_batch_stride; p.gbs = a->gate_batch_stride; p.obs = a->out_batch_stride;
+    p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
+    p.kv_len = a->kv_len; p.q_len = a->q_len;
+    p.scale = a->scale; p.clamp = a->softclamp;
+    p.dbg = v2a_detail::g_probe_dbg;
+    g.hstart[j] = htot;
+    htot += a->H;
+  }
+  for (int j = nprob; j <= kAttnGroupMax; ++j) g.hstart[j] = 0x7fffffff;
+  const v2a_attn_args* a = args;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g64((a->Nq + 63) / 64, htot, a->B);
+  const int cl = attn_clamp_mode(a->softclamp, a->Nk);
+  const bool split_kv = a->Nk > 128 && (int64_t)g64.x * g64.y * g64.z < v2a_detail::g_attn_one_group_from;
+  if (split_kv) {
+    if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<2, 2, true>), g64, dim3(512), 0, s, g);
+    else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<2, 1, true>), g64, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((attn_mfma_kernel<2, 0, true>), g64, dim3(512), 0, s, g);
+  } else {
+    if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<1, 2, true>), g64, dim3(256), 0, s, g);
+    else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<1, 1, true>), g64, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((attn_mfma_kernel<1, 0, true>), g64, dim3(256), 0, s, g);
+  }
+  return v2a_check_launch("v2a_attention_grouped");
 }

@@ -190,8 +190,18 @@ __device__ __forceinline__ void ring_wait(int younger) {
 //   acc += A_lo W_hi + A_hi W_lo + A_hi W_hi   (fp32-grade product, relative error ~2^-16),
 // so a K step moves 2x the bytes of a bf16 step for 3x its flops -- where the three-segment form on the plain kernel
 // ([A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]) moved 3x the bytes and needed one launch per logical K segment.
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParams p) {
+// GROUPED: the argument is a GemmGroup and the workgroup first picks its problem (gemm_common.h); everything after that is the
+// single-problem kernel on that problem's parameter block.
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false, bool GROUPED = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const std::conditional_t<GROUPED, v2a_detail::GemmGroup, GemmParams> arg) {
+  int bid_ = blockIdx.x;
+  const GemmParams* pp_;
+  if constexpr (GROUPED) pp_ = &group_pick(arg, bid_);
+  else pp_ = &arg;
+  const GemmParams& p = *pp_;
+  if constexpr (GROUPED) {
+    if (bid_ >= p.tiles_m * p.tiles_n) return;       // padding between the problems of a group (starts are multiples of 8)
+  }
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(GemmParam
     if (L < 0) return;
     tile_of_index(p, L, tm, tn);
   } else {
-    tile_of_block(p, blockIdx.x, tm, tn);
+    tile_of_block(p, bid_, tm, tn);
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -531,6 +541,40 @@ int dispatch_s3(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
   return v2a_fail(V2A_ERR_ARG, "v2a_gemm(split bf16): unsupported epilogue %d / out_dtype %d for this tile shape", a->epilogue, a->out_dtype);
 }
 
+// ---- grouped launches (v2a_gemm_grouped) -----------------------------------------------------------------------------------
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST, bool S3 = false>
+int launch_dma_grouped(v2a_detail::GemmGroup& g, hipStream_t s) {
+  int total = 0;
+  for (int j = 0; j < g.nprob; ++j) {
+    v2a_detail::fill_tile_map(g.p[j], BM, BN);
+    V2A_REQUIRE((int64_t)g.p[j].tiles_m * g.p[j].tiles_n < (1 << 24), "v2a_gemm_grouped: %d x %d tiles exceed the tile map", g.p[j].tiles_m, g.p[j].tiles_n);
+    g.start[j] = total;
+    total += (g.p[j].tiles_m * g.p[j].tiles_n + 7) / 8 * 8;
+  }
+  for (int j = g.nprob; j <= v2a_detail::kGroupMax; ++j) g.start[j] = 0x7fffffff;
+  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 * (S3 ? 2 : 1) + BM * 4 + 16;
+  static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
+  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3, true>;
+  static std::atomic<uint64_t> lds_set{0};
+  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm_grouped(dma)")) return rc;
+  hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WGM * WGN), smem, s, g);
+  return v2a_check_launch("v2a_gemm_grouped(dma)");
+}
+
+// epi: V2A_EPI_STORE (bf16 out), V2A_EPI_GEGLU (bf16 out) or V2A_EPI_GATE_RESID (fp32 out; problems without a gate / residual run
+// through it with the absent operands read as 1 / 0)
+template <int BM, int BN, int WGM, int WGN, int NST = 3>
+int dispatch_grouped(v2a_detail::GemmGroup& g, int epi, hipStream_t s) {
+  switch (epi) {
+    case V2A_EPI_STORE: return launch_dma_grouped<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN, NST>(g, s);
+    case V2A_EPI_GEGLU:
+      if constexpr ((BN / WGN / 16) % 2 == 0) return launch_dma_grouped<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST>(g, s);
+      break;
+    case V2A_EPI_GATE_RESID: return launch_dma_grouped<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST>(g, s);
+  }
+  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped: epilogue %d on this tile shape", epi);
+}
+
 }  // namespace
 
 // defaults: phase-interleaved 256x256 kernel for wide outputs once a launch has >= 400 tiles, i.e. from two clips per GPU on
@@ -571,7 +615,8 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
   return V2A_OK;
 }
 
-extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
+// argument checks + the kernel parameter block of one problem (shared by v2a_gemm and v2a_gemm_grouped)
+static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
   V2A_REQUIRE(a != nullptr, "v2a_gemm: null args");
   V2A_REQUIRE(a->nseg >= 1 && a->nseg <= 3, "v2a_gemm: nseg=%d", a->nseg);
   V2A_REQUIRE(a->M > 0 && a->N > 0, "v2a_gemm: M=%d N=%d", a->M, a->N);
@@ -581,7 +626,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
               "v2a_gemm: A dtype %d with compute dtype %d", a->a_dtype, a->compute_dtype);
   const int bk = a->compute_dtype == V2A_BF16 ? 64 : 16;
   const int a_vec = a->a_dtype == V2A_F32 ? 4 : 8;  // elements per 16-byte load
-  GemmParams p{};
+  p = GemmParams{};
   int K = 0;
   for (int s = 0; s < a->nseg; ++s) {
     V2A_REQUIRE(a->a[s] != nullptr, "v2a_gemm: segment %d null", s);
@@ -719,6 +764,15 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     V2A_REQUIRE(a->resid != nullptr, "v2a_gemm: epilogue %d needs resid", a->epilogue);
   if (a->epilogue == V2A_EPI_GATE_RESID) V2A_REQUIRE(a->gate != nullptr, "v2a_gemm: GATE_RESID needs gate");
   if (a->epilogue == V2A_EPI_GEGLU) V2A_REQUIRE(a->N % 32 == 0, "v2a_gemm: GEGLU needs N %% 32 == 0 (N=%d)", a->N);
+  return V2A_OK;
+}
+
+extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
+  GemmParams p;
+  if (int rc = gemm_prepare(a, p)) return rc;
+  const bool split_in = a->a_dtype == V2A_BF16_SPLIT;
+  const int K = p.K;
+  const v2a_detail::GemmTuning tune = v2a_detail::g_gemm_tuning;
   hipStream_t s = (hipStream_t)stream;
   if (a->compute_dtype == V2A_F32) {
     // exact-fp32 kernel: 64x64 tiles while 128x128 ones would leave CUs idle (one clip: 13 x 8 tiles for N = 1024); the K order of
@@ -836,4 +890,62 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     case 8: return dispatch_dma<64, 64, 2, 2, 6>(a, p, s);  // 4 waves,  96 KB: 6-deep ring, 1 workgroup/CU (<= 256 tiles)
     default: return dispatch_dma<64, 64, 2, 2>(a, p, s);    // 4 waves,  48 KB, 3 workgroups/CU
   }
+}
+
+// Up to three independent problems in one launch (the same op of the audio / text / frames blocks of a layer).
+extern "C" int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_stream_t stream) {
+  V2A_REQUIRE(args != nullptr && nprob >= 1 && nprob <= v2a_detail::kGroupMax, "v2a_gemm_grouped: %d problems (1..%d)", nprob, v2a_detail::kGroupMax);
+  if (nprob == 1) return v2a_gemm(args, stream);
+  // the epilogue of the group: all STORE to bf16 (+ RoPE), all GEGLU to bf16, or fp32 results with any mix of STORE / RESID / GATE_RESID
+  const int e0 = args[0].epilogue;
+  const bool resid_family = e0 == V2A_EPI_RESID || e0 == V2A_EPI_GATE_RESID || (e0 == V2A_EPI_STORE && args[0].out_dtype == V2A_F32);
+  const int epi = resid_family ? V2A_EPI_GATE_RESID : e0;
+  V2A_REQUIRE(epi == V2A_EPI_STORE || epi == V2A_EPI_GEGLU || epi == V2A_EPI_GATE_RESID, "v2a_gemm_grouped: epilogue %d", e0);
+  v2a_detail::GemmGroup g{};
+  g.nprob = nprob;
+  int order[v2a_detail::kGroupMax];
+  GemmParams tmp[v2a_detail::kGroupMax];
+  for (int j = 0; j < nprob; ++j) {
+    const v2a_gemm_args* a = args + j;
+    if (int rc = gemm_prepare(a, tmp[j])) return rc;
+    V2A_REQUIRE(a->compute_dtype == V2A_BF16 && a->a_dtype == V2A_BF16 && tmp[j].vec_epi && !a->a_row_offset && !a->out_row_offset && !a->relu &&
+                    !(a->xcd_mask && (a->xcd_mask & 0xFF) != 0xFF),
+                "v2a_gemm_grouped: problem %d must be bf16 x bf16 with dense rows and 16-byte aligned epilogue operands", j);
+    if (resid_family)
+      V2A_REQUIRE(a->out_dtype == V2A_F32 && (a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID || a->epilogue == V2A_EPI_STORE) && !a->rope_table,
+                  "v2a_gemm_grouped: problem %d: fp32 STORE / RESID / GATE_RESID problems group together (epilogue %d)", j, a->epilogue);
+    else
+      V2A_REQUIRE(a->epilogue == epi && a->out_dtype == V2A_BF16, "v2a_gemm_grouped: problem %d: epilogue %d / out dtype %d differs from the group's", j,
+                  a->epilogue, a->out_dtype);
+    if (resid_family && a->epilogue == V2A_EPI_STORE) tmp[j].resid = nullptr;
+    if (resid_family && a->epilogue != V2A_EPI_GATE_RESID) tmp[j].gate = nullptr;
+    V2A_REQUIRE(a->tile_hint == args[0].tile_hint, "v2a_gemm_grouped: one tile_hint for the whole group");
+    order[j] = j;
+  }
+  // longest K first (stable): see GemmGroup
+  for (int i = 1; i < nprob; ++i)
+    for (int j = i; j > 0 && tmp[order[j]].K > tmp[order[j - 1]].K; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  for (int j = 0; j < nprob; ++j) g.p[j] = tmp[order[j]];
+  hipStream_t s = (hipStream_t)stream;
+  // tile shape: tile_hint k + 1 = configuration k as for v2a_gemm (7 = the 256x256 8-phase kernel); 0 = by the widest output of the group
+  int cfg = args[0].tile_hint - 1;
+  if (cfg < 0) {
+    int64_t t256 = 0;
+    int nmax = 0;
+    for (int j = 0; j < nprob; ++j) {
+      t256 += (int64_t)((g.p[j].M + 255) / 256) * ((g.p[j].N + 255) / 256);
+      nmax = g.p[j].N > nmax ? g.p[j].N : nmax;
+    }
+    cfg = (nmax >= 2048 && t256 >= 150 && v2a_detail::g_gemm_tuning.use_8phase) ? 6 : 12;
+  }
+  switch (cfg) {
+    case 6: return v2a_detail::launch_gemm_8phase_grouped(g, epi, epi == V2A_EPI_GATE_RESID ? V2A_F32 : V2A_BF16, s);
+    case 0: return dispatch_grouped<128, 256, 2, 4>(g, epi, s);
+    case 1: return dispatch_grouped<128, 128, 2, 2>(g, epi, s);
+    case 3: return dispatch_grouped<64, 64, 2, 2>(g, epi, s);
+    case 12: return dispatch_grouped<128, 128, 2, 4, 3>(g, epi, s);
+    case 14: return dispatch_grouped<128, 64, 4, 2, 3>(g, epi, s);
+    case 15: return dispatch_grouped<64, 128, 2, 4, 3>(g, epi, s);
+  }
+  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped: tile_hint %d (supported: 0, 1, 2, 4, 7, 13, 15, 16)", args[0].tile_hint);
 }

@@ -38,8 +38,16 @@ constexpr int kSkip = 0;
 // was 2-3 % faster per launch only while its DMAs were issued in the read blocks, where the wave row that runs one barrier behind may
 // still have fragment reads of the restaged half tile in flight: safe by timing, not by a barrier.  Issued behind the barriers that make
 // it safe by construction it was 10-15 % slower than four phases: profiles/r03_8phase_two_phase_mode.txt.  Four phases stay.)
-template <int EPI, typename OutT, int MODE>
-__global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
+template <int EPI, typename OutT, int MODE, bool GROUPED = false>
+__global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const std::conditional_t<GROUPED, v2a_detail::GemmGroup, GemmParams> arg) {
+  int bid_ = blockIdx.x;
+  const GemmParams* pp_;
+  if constexpr (GROUPED) pp_ = &group_pick(arg, bid_);      // grouped launch: this workgroup's problem (gemm_common.h)
+  else pp_ = &arg;
+  const GemmParams& p = *pp_;
+  if constexpr (GROUPED) {
+    if (bid_ >= p.tiles_m * p.tiles_n) return;
+  }
   constexpr bool STAGGER = MODE != 2;
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, TM = 8, TN = 4;
   constexpr int HALF = 128 * 128;               // bytes of a half tile
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   const int lr = lane & 15, lq = lane >> 4;
 
   int tm, tn;
-  tile_of_block(p, blockIdx.x, tm, tn);
+  tile_of_block(p, bid_, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[TM][TN];
@@ -257,7 +265,39 @@ int launch_8ph(const GemmParams& p_in, hipStream_t s) {
   return v2a_check_launch("v2a_gemm(8-phase)");
 }
 
+template <int EPI, typename OutT>
+int launch_8ph_grouped(v2a_detail::GemmGroup& g, hipStream_t s) {
+  int total = 0;
+  for (int j = 0; j < g.nprob; ++j) {
+    v2a_detail::fill_tile_map(g.p[j], 256, 256);
+    g.start[j] = total;
+    total += (g.p[j].tiles_m * g.p[j].tiles_n + 7) / 8 * 8;
+  }
+  for (int j = g.nprob; j <= v2a_detail::kGroupMax; ++j) g.start[j] = 0x7fffffff;
+  constexpr size_t smem = 2 * 4 * 128 * 128 + 256 * 4;
+  auto kern = gemm_bf16_8ph_kernel<EPI, OutT, 1, true>;
+  static std::atomic<uint64_t> lds_set{0};
+  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm_grouped(8-phase)")) return rc;
+  hipLaunchKernelGGL(kern, dim3(total), dim3(512), smem, s, g);
+  return v2a_check_launch("v2a_gemm_grouped(8-phase)");
+}
+
 }  // namespace
+
+int v2a_detail::launch_gemm_8phase_grouped(GemmGroup& g, int epilogue, int out_dtype, hipStream_t s) {
+  switch (epilogue) {
+    case V2A_EPI_STORE:
+      if (out_dtype == V2A_BF16) return launch_8ph_grouped<V2A_EPI_STORE, bf16_t>(g, s);
+      break;
+    case V2A_EPI_GEGLU:
+      if (out_dtype == V2A_BF16) return launch_8ph_grouped<V2A_EPI_GEGLU, bf16_t>(g, s);
+      break;
+    case V2A_EPI_GATE_RESID:
+      if (out_dtype == V2A_F32) return launch_8ph_grouped<V2A_EPI_GATE_RESID, float>(g, s);
+      break;
+  }
+  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped(8-phase): unsupported epilogue %d / out_dtype %d", epilogue, out_dtype);
+}
 
 int v2a_detail::launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStream_t s) {
   const bool out_f32 = out_dtype == V2A_F32;

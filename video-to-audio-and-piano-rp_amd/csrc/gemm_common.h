@@ -68,6 +68,19 @@ struct GemmParams {
   int32_t dbg;              // probe builds only (-DV2A_GEMM_PROBE, scripts/probes/kloop_probe.py): K-loop parts switched off by bit
 };
 
+// Grouped launch (v2a_gemm_grouped): up to three independent problems behind ONE kernel launch -- the same op of the audio, text and
+// frames blocks of a layer, whose workgroups then fill the chip together instead of queueing on three streams.  Workgroup bid belongs
+// to problem j = the last one with start[j] <= bid and computes tile bid - start[j] of it (starts are multiples of 8 so that
+// bid & 7, the XCD label of the tile order, is the physical one; a workgroup past the problem's tile count leaves at once).
+// The host orders the problems by K, longest first: the dispatcher hands workgroups out in index order, so when the group does not
+// fit the chip in one round the short tiles are the ones that wait.
+constexpr int kGroupMax = 3;
+struct GemmGroup {
+  int32_t nprob;
+  int32_t start[kGroupMax + 1];
+  GemmParams p[kGroupMax];
+};
+
 // tile-shape selectors of the LDS-DMA bf16 kernels (v2a_set_tuning)
 struct GemmTuning {
   int force_tile;        // -1 = by shape
@@ -85,6 +98,7 @@ extern int g_dwconv_stream;          // 0: never use the streaming depthwise con
 
 // 256x256 8-phase kernel (gemm_8phase.hip)
 int launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
+int launch_gemm_8phase_grouped(GemmGroup& g, int epilogue, int out_dtype, hipStream_t stream);
 
 // host: the gm x gn rectangles of the tile space for a BM x BN tile shape (xcd_gm / xcd_gn chosen by v2a_gemm)
 inline void fill_tile_map(GemmParams& p, int BM, int BN) {
@@ -143,6 +157,13 @@ __device__ __forceinline__ void tile_of_block(const GemmParams& p, int bid, int&
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);      // bijective: position in the linear order
   tile_of_index(p, L, tm, tn);
+}
+
+// grouped launch: the problem of workgroup `bid` and its index inside that problem (all wave-uniform: scalar compares and selects)
+__device__ __forceinline__ const GemmParams& group_pick(const v2a_detail::GemmGroup& g, int& bid) {
+  const int j = (bid >= g.start[1] ? 1 : 0) + (bid >= g.start[2] ? 1 : 0);
+  bid -= g.start[j];
+  return g.p[j];
 }
 
 // XCD-subset placement: the physical XCD of this workgroup (HW_REG_XCC_ID, bits 3:0)
@@ -309,6 +330,7 @@ template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
       // kernel arguments copied once: the loops below stay free of scalar re-loads and branches
       const int M = p.M;
       const bool full = n + 3 < p.N;
+      const bool has_res = p.resid != nullptr, has_gate = p.gate != nullptr;     // wave-uniform
       const float* resid = p.resid + n;
       const int64_t ldr = p.ldr;
       const int32_t* orow = SCAT ? p.o_rowoff : nullptr;
@@ -333,8 +355,10 @@ template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
           if (m < M && full) {
             int64_t off = (int64_t)m * ldr;
             if constexpr (SCAT) { if (orow) off = ro[i][q]; }
-            rs[i][q] = *reinterpret_cast<const f32x4*>(resid + off);
-            if constexpr (GATE) gt[i][q] = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0) + n);
+            // a grouped launch runs problems with and without a residual / gate through one instantiation: absent operands read as
+            // 0 / 1 (resid + 1 * acc is exactly the RESID epilogue, 0 + 1 * acc the plain store)
+            rs[i][q] = has_res ? *reinterpret_cast<const f32x4*>(resid + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (GATE) gt[i][q] = has_gate ? *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0) + n) : f32x4{1.f, 1.f, 1.f, 1.f};
           }
         }
     }
@@ -509,8 +533,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
             rs = pf.rs[i][q];
             if constexpr (EPI == V2A_EPI_GATE_RESID) gt = pf.gt[i][q];
           } else {
-            rs = *reinterpret_cast<const f32x4*>(resid + o_res + n);
-            if constexpr (EPI == V2A_EPI_GATE_RESID) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0) + n);
+            rs = resid ? *reinterpret_cast<const f32x4*>(resid + o_res + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == V2A_EPI_GATE_RESID) {
+              if (p.gate) gt = *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0) + n);
+            }
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rs[e] + gt[e] * v[e];
