@@ -106,6 +106,8 @@ def main():
                     "disjoint bit ranges); needs --no-graph (a replayed multi-stream hipGraph does not keep stream masks)")
     ap.add_argument("--main-tile", type=int, default=-1, help="A/B: GEMM tile configuration of the audio stream's narrow-output GEMMs (-1 library choice)")
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
+    ap.add_argument("--no-grouped", action="store_true", help="A/B: the three-stream schedule of single launches instead of the chain of grouped launches")
+    ap.add_argument("--group-tiles", default="", help="A/B: tile_hint per grouped launch, e.g. cross=13,qkv=7,out=13,ff1=7,ff2=13 (0 = by shape)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the supplementary configs[3] (V2P) and configs[4] (cascade) legs")
     ap.add_argument("--graph-roofline", action="store_true", help="try to time kernels with events between graph nodes (not available on ROCm 7.0 torch)")
@@ -164,6 +166,11 @@ def main():
             key, val = item.split("=")
             st_, op_ = key.split(".")
             table[(st_, op_)] = int(val)
+    if args.no_grouped:
+        model.engine().grouped = False
+    for item in filter(None, args.group_tiles.split(",")):
+        key, val = item.split("=")
+        model.engine().group_tiles[key] = int(val)
     if args.no_fold_norm:
         model.engine().fold_norm = False
     if args.no_fuse_skip:
@@ -278,7 +285,9 @@ def main():
                                % (3 if args.v2p else (4 if args.cascade > 1 else (1 if B == 1 else 2)), B, T, cfm_steps, evals, 2 * evals, NC,
                                   "V2P roll" if args.v2p else "V2A zero roll"),
                    "clips_per_gpu": B, "global_clips": n_clips, "parallelism": "clip-sharded x%d, 1 all-gather" % world,
-                   "hipgraph": not args.no_graph, "side_streams": not args.single_stream, "cascade_passes": args.cascade},
+                   "hipgraph": not args.no_graph, "schedule": ("one chain of grouped launches" if model.engine()._use_grouped() else
+                                                               ("single stream" if args.single_stream else "three streams")),
+                   "side_streams": not args.single_stream and not model.engine()._use_grouped(), "cascade_passes": args.cascade},
         "per_gpu_mel_frames_per_s": round(frames_per_s / world, 2),
         "clips_per_s": round(n_clips / (el / args.steps), 4),
         "ms_per_cfg_evaluation": round(ms_per_step / evals / args.cascade, 4),

@@ -251,6 +251,26 @@ def test_config4_cascade_equals_independent_calls(full, mbf):
     assert not torch.equal(casc[0], casc[1])
 
 
+@pytest.mark.parametrize("clips,ragged", [(1, False), (2, True)])
+def test_grouped_schedule_equals_three_streams_at_full_shape(full, mbf, clips, ragged):
+    """bf16 mode at the shipped widths (the per-group tile table applies at one clip): the chain of grouped launches against the
+    three-stream schedule of single launches, equal bit for bit."""
+    f = full
+    y0, text, roll, ctx, cm = O.synthetic_inputs(f["cfg"], clips, 750, nc=16, seed=5, piano=True)
+    kw = dict(y0=y0, text_embed=text, context=ctx, context_mask=cm, frames_embed=roll, return_raw_output=True, steps=4, cfg_strength=2.0,
+              remove_parallel_component=False)
+    if ragged:
+        kw.update(lens=torch.tensor([750, 611]), duration=torch.tensor([750, 611]))
+    outs = []
+    for grouped in (True, False):
+        mbf.engine().grouped = grouped
+        outs.append(mbf.sample(torch.zeros(clips, 750, 128), **kw).float().cpu())
+        assert mbf.engine()._use_grouped() == grouped
+    mbf.engine().grouped = True
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("clips,ragged", [(1, False), (2, True)])
 def test_bf16_one_launch_cross_attention_equals_two_launches(full, mbf, clips, ragged, mode):

@@ -302,9 +302,12 @@ def gemm_grouped(built, tile_hint=0):
     for i, (g, _, _, _) in enumerate(built):
         C.memmove(C.byref(arr[i]), C.byref(g), C.sizeof(GemmArgs))
         arr[i].tile_hint = tile_hint
-    epi = {b[0].epilogue for b in built}
-    key = "gemm_grouped<%s,%s%s>" % ("+".join(sorted(_EPI_NAMES[e] for e in epi)), "f32" if built[0][0].out_dtype == F32 else "bf16",
-                                     ",tile%d" % (tile_hint - 1) if tile_hint else "")
+    # the instantiation the group runs on: fp32 results go through the GATE_RESID epilogue whatever mix of STORE / RESID / GATE_RESID they are
+    f32 = built[0][0].out_dtype == F32
+    key = "gemm_grouped<bf16,a_bf16,%s,%s%s>" % ("gate_resid" if f32 else _EPI_NAMES[built[0][0].epilogue], "f32" if f32 else "bf16",
+                                                 ",tile%d" % (tile_hint - 1) if tile_hint else "")
+    if _prof is not None and _prof.shapes:
+        key += " " + "|".join(b[1].rsplit(" ", 1)[-1] for b in built)
     _launch(key, sum(b[2] for b in built), sum(b[3] for b in built), lambda: lib().v2a_gemm_grouped(arr, n, stream_ptr()))
 
 

@@ -1053,7 +1053,11 @@ extern "C" int v2a_attention_grouped(const v2a_attn_args* args, int32_t nprob, v
   hipStream_t s = (hipStream_t)stream;
   const dim3 g64((a->Nq + 63) / 64, htot, a->B);
   const int cl = attn_clamp_mode(a->softclamp, a->Nk);
-  const bool split_kv = a->Nk > 128 && (int64_t)g64.x * g64.y * g64.z < v2a_detail::g_attn_one_group_from;
+  // one or two wave groups per workgroup: what v2a_attention would pick for the LARGEST problem alone, so that a problem's result does
+  // not depend on what it is grouped with (the two-group form merges two partial sums: same value up to rounding, not bit for bit)
+  int hmax = 0;
+  for (int j = 0; j < nprob; ++j) hmax = args[j].H > hmax ? args[j].H : hmax;
+  const bool split_kv = a->Nk > 128 && (int64_t)g64.x * hmax * g64.z < v2a_detail::g_attn_one_group_from;
   if (split_kv) {
     if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<2, 2, true>), g64, dim3(512), 0, s, g);
     else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<2, 1, true>), g64, dim3(512), 0, s, g);

@@ -262,6 +262,15 @@ class DiTEngine:
         # bf16 and bf16x3 modes, up to three clips (bf16 stand-alone: 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
         # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
         self.fuse_xattn = True
+        # Round 4: ONE chain of grouped launches instead of three streams (bf16 mode while a launch cannot fill the chip, i.e. up to two
+        # clips): the audio block of layer i and the text / frames blocks of layer i+1 are independent and run the same op sequence
+        # (x3:1081-1137), so each op of the three is ONE launch (v2a_gemm_grouped / v2a_attention_grouped / v2a_dwconv_grouped) whose
+        # workgroups fill the chip together -- no cross-stream hand-offs, no kernels queueing behind another stream's fat workgroups
+        # (the three-stream schedule ran every kernel ~1.5x its stand-alone time: profiles/r03_timeline_multistream.txt).
+        self.grouped = True
+        # tile_hint of each grouped launch (cfg + 1 of v2a_gemm's tile configurations; 7 = the 256x256 8-phase kernel, 13 = 128x128 with
+        # eight waves): measured per group with `bench.py --group-tiles` (profiles/r04_group_tiles.txt)
+        self.group_tiles = {"cross": 13, "qkv": 7, "out": 13, "ff1": 7, "ff2": 13}
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
@@ -384,7 +393,7 @@ class DiTEngine:
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
                 tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
-                self.interleave_capture, self.rope_cross, self.zero_masked_queries)
+                self.grouped, tuple(sorted(self.group_tiles.items())), self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
     def _sh(self, buf):
@@ -408,6 +417,19 @@ class DiTEngine:
         if kw.get("out_bf16") is not None:
             kw["out_bf16_split"] = True
         return L.gemm(segs, W, out, compute=L.BF16, a_split=True, **kw)
+
+    def _mm_args(self, segs, W, out, **kw):
+        """The v2a_gemm argument block of one problem of a grouped launch (bf16 mode: plain operands)."""
+        assert not self.split
+        if kw.get("out_bf16") is not None and "ld_out_bf16" not in kw:
+            kw["ld_out_bf16"] = kw["out_bf16"].stride(-2)
+        return L.gemm_args(segs, W, out, compute=self.cdc, **kw)
+
+    def _use_grouped(self):
+        """Grouped single-chain schedule: bf16 operands, every RMSNorm folded into its neighbours (so a block is conv, QKV, attention,
+        out, feed-forward in / out and nothing else), fused RoPE, and launches that cannot fill the chip on their own (<= 2 clips)."""
+        return (self.grouped and self.dev.type == "cuda" and self.cd == torch.bfloat16 and not self.split and self._fold_gemm()
+                and self._fuse_rope and self.adc == L.BF16)
 
     def _norm_plain(self, x, hn, rows, d, g):
         L.rmsnorm(x, hn, rows=rows, d=d, gamma=g, split=self.split)
@@ -569,6 +591,57 @@ class DiTEngine:
                 self._norm_plain(dst, hn, rows, d, ly[f"{s}_g2"])
             self._ff(ly[f"{s}_ff"], dst, s, nseq, d, dict(epilogue=L.EPI_RESID, **h2), cons2)
 
+    def _audio_cross_attention(self, i, ly, x, nctx, cons2, fold2, lens):
+        """x[:nctx] += gate * to_out(attend(q(x), K_ctx, V_ctx)) of layer i (x3:1126-1133) on the current stream: one launch
+        (v2a_qproj_xattn) + the out-projection, or q-projection, (RoPE,) attention, out-projection."""
+        p, c, W = self.plan, self.cfg, self.W
+        N, D = p["N"], c.dim
+        inner = c.heads * c.dim_head
+        nkv = 2 * c.depth * inner
+        mh = self._main_hint
+        r2 = nctx * N
+        A2 = ly["a_attn2"]
+        if not fold2:
+            self._norm_ada(x, p["hn_a"], r2, D, i, 1)
+        q2 = p["q2"]
+        es = q2.element_size()
+        kb = p["ctx_kv"].data_ptr() + i * inner * es
+        vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
+        aw = p["ao_a"].stride(-2)
+        # one launch while its 64-token x one-head workgroups stay under ~2.75 per CU (three clips at the shipped dims: 624; four clips
+        # -- 832 -- are faster as two launches on larger tiles, profiles/r03_xattn_probe.txt)
+        one_launch = (self.fuse_xattn and self.adc in (L.BF16, L.BF16_SPLIT) and nctx * -(-N // 64) * A2.heads <= 704 and p["nc"] <= 64 and D % 512 == 0
+                      and A2.gate_col == A2.inner and (self._fuse_rope or not self.rope_cross))
+        if one_launch:
+            rk = dict(rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0) if self.rope_cross else {}
+            nk = dict(row_ssq=cons2["row_ssq"], row_norm_dim=cons2["row_norm_dim"]) if cons2 else {}
+            L.qproj_xattn(p["hn_a"], p["hn_a"].stride(-2) if self.split else D, D, A2.w_in, bias=A2.b_in, M=r2, N=A2.n_pad, rows_per_batch=N,
+                          k=kb, v=vb, out=p["ao_a"].data_ptr(), split=self.split,
+                          kv_strides=(nkv, nkv, p["nc"] * nkv, p["nc"] * nkv), out_strides=(aw, N * aw), B=nctx, H=A2.heads, Nk=p["nc"],
+                          kv_len=p["ctx_len"], q_len=lens if self.zero_masked_queries else None, scale=c.dim_head ** -0.5,
+                          softclamp=self.softclamp, **rk, **nk)
+        elif self.rope_cross and self._fuse_rope:
+            self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad,
+                     rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons2, **mh("q2"))
+        else:
+            self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad, **cons2, **mh("q2"))
+            if self.rope_cross:
+                L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
+                       table=p["rope"], layout=self.rope_layout)
+        if not one_launch:
+            L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, p["ao_a"].data_ptr(),
+                        strides=(A2.n_pad, nkv, nkv, A2.n_pad, aw,
+                                 N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * aw),
+                        B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
+                        q_len=lens if self.zero_masked_queries else None,
+                        scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
+        prod2 = {}
+        if fold2:
+            n2 = {k: v for k, v in self._nprod_ada(i, 2).items() if k not in ("step", "rows_per_batch")}
+            prod2 = dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), **n2)
+        self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
+                 epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh("out2"), **prod2)
+
     # ------------------------------------------------------------------------------ prepare
     def prepare(self, text, frames_roll, context, context_mask, t_points, *, lens=None,
                 drop_text=None, drop_ctx=None, dt=None, step_cond=None, rope_len=None, rope_ctx_len=None):
@@ -686,6 +759,8 @@ class DiTEngine:
         layer), x of the layer ready (eA -> the side streams' own cross-condition GEMMs) and main's cross-condition GEMM
         done (eX -> the side blocks may overwrite the text / frames buffers it read).  All are forward edges: the main
         stream (the critical path) waits only for eT / eF, which the side streams reach with slack."""
+        if self._use_grouped():
+            return self.forward_grouped(n_ctx_seqs)
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
         D, Dt, Df = c.dim, c.dim_text, c.dim_frames
@@ -819,47 +894,7 @@ class DiTEngine:
                             wait(sf, eX)
                         self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df, (part,))
             if nctx > 0:
-                A2 = ly["a_attn2"]
-                if not fold2:
-                    self._norm_ada(x, p["hn_a"], r2, D, i, 1)
-                q2 = p["q2"]
-                es = q2.element_size()
-                kb = p["ctx_kv"].data_ptr() + i * inner * es
-                vb = p["ctx_kv"].data_ptr() + (c.depth + i) * inner * es
-                aw = p["ao_a"].stride(-2)
-                # one launch while its 64-token x one-head workgroups stay under ~2.75 per CU (three clips at the shipped dims: 624; four clips
-                # -- 832 -- are faster as two launches on larger tiles, profiles/r03_xattn_probe.txt)
-                one_launch = (self.fuse_xattn and self.adc in (L.BF16, L.BF16_SPLIT) and nctx * -(-N // 64) * A2.heads <= 704 and p["nc"] <= 64 and D % 512 == 0
-                              and A2.gate_col == A2.inner and (self._fuse_rope or not self.rope_cross))
-                if one_launch:
-                    rk = dict(rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0) if self.rope_cross else {}
-                    nk = dict(row_ssq=cons2["row_ssq"], row_norm_dim=cons2["row_norm_dim"]) if cons2 else {}
-                    L.qproj_xattn(p["hn_a"], p["hn_a"].stride(-2) if self.split else D, D, A2.w_in, bias=A2.b_in, M=r2, N=A2.n_pad, rows_per_batch=N,
-                                  k=kb, v=vb, out=p["ao_a"].data_ptr(), split=self.split,
-                                  kv_strides=(nkv, nkv, p["nc"] * nkv, p["nc"] * nkv), out_strides=(aw, N * aw), B=nctx, H=A2.heads, Nk=p["nc"],
-                                  kv_len=p["ctx_len"], q_len=lens if self.zero_masked_queries else None, scale=c.dim_head ** -0.5,
-                                  softclamp=self.softclamp, **rk, **nk)
-                elif self.rope_cross and self._fuse_rope:
-                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad,
-                             rope_table=p["rope"], rope_cols=A2.inner, rope_pos_offset=0, rows_per_batch=N, **cons2, **mh("q2"))
-                else:
-                    self._mm([(p["hn_a"], D, D)], A2.w_in, q2, M=r2, N=A2.n_pad, bias=A2.b_in, ldo=A2.n_pad, **cons2, **mh("q2"))
-                    if self.rope_cross:
-                        L.rope(q2, rows=r2, row_stride=A2.n_pad, nheads=A2.heads, rows_per_batch=N, pos_offset=0,
-                               table=p["rope"], layout=self.rope_layout)
-                if not one_launch:
-                    L.attention(q2.data_ptr(), kb, vb, q2.data_ptr() + A2.gate_col * es, p["ao_a"].data_ptr(),
-                                strides=(A2.n_pad, nkv, nkv, A2.n_pad, aw,
-                                         N * A2.n_pad, p["nc"] * nkv, p["nc"] * nkv, N * A2.n_pad, N * aw),
-                                B=nctx, H=A2.heads, Nq=N, Nk=p["nc"], kv_len=p["ctx_len"],
-                                q_len=lens if self.zero_masked_queries else None,
-                                scale=c.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
-                prod2 = {}
-                if fold2:
-                    n2 = {k: v for k, v in self._nprod_ada(i, 2).items() if k not in ("step", "rows_per_batch")}
-                    prod2 = dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), **n2)
-                self._mm([(p["ao_a"], inner, inner)], A2.w_out, x, M=r2, N=D, resid=x, ldo=D, ldr=D,
-                         epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 1), **mh("out2"), **prod2)
+                self._audio_cross_attention(i, ly, x, nctx, cons2, fold2, lens)
             if not fold2:
                 self._norm_ada(x, p["hn_a"], rows, D, i, 2)
             # the bf16 copy of this layer's output: into the wide buffer of the next layer's skip when that layer is fused
@@ -893,6 +928,140 @@ class DiTEngine:
         else:
             L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g, split=self.split)
             self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels)
+        return p["pred"]
+
+    def forward_grouped(self, n_ctx_seqs: int | None = None):
+        """Transformer.forward as ONE chain of grouped launches (bf16 mode, up to two clips; see `grouped` in __init__).  Per layer i the
+        chain is: cross-condition {x_tfa_i | x_at_i | x_af_i}, conv {A_i | T_i+1 | F_i+1}, QKV, self-attention, out-projection, the audio
+        block's cross-attention (two launches of its own), feed-forward in, feed-forward out -- 9 launches instead of ~25 on three
+        streams.  Same kernels, same arithmetic per problem as forward(): the results are equal bit for bit
+        (tests/test_sampler_gpu.py::test_grouped_schedule_equals_three_streams)."""
+        p, c, W = self.plan, self.cfg, self.W
+        B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
+        D, Dt, Df = c.dim, c.dim_text, c.dim_frames
+        nctx = B if n_ctx_seqs is None else n_ctx_seqs
+        lens = p["seq_len"] if p["ragged"] else None
+        half = c.depth // 2
+        fz = self._fuse_skip()
+        xc, xo = p["xA"], p["xB"]
+        tc_, fc_ = p["tL0"], p["fL0"]
+        tbuf, fbuf = [p["tA"], p["tB"]], [p["fA"], p["fB"]]
+        # the per-group tile table was measured at one clip of the shipped widths; elsewhere the library picks by the group's shape
+        gt = self.group_tiles if (self._regime() == 0 and self._tuned_dims()) else {}
+        scale = c.dim_head ** -0.5
+        zq = lens if self.zero_masked_queries else None
+
+        def launch(G, op, main_op):
+            # a group of one (the last layer has no text / frames blocks) keeps the audio stream's own tile choice
+            if len(G) == 1:
+                L.gemm_grouped(G, tile_hint=self._main_hint(main_op).get("tile_hint", 0))
+            else:
+                L.gemm_grouped(G, tile_hint=gt.get(op, 0))
+
+        def qkv_args(A, s, d, nc):
+            hn, qkv = p[f"hn_{s}"], p[f"qkv_{s}"]
+            return self._mm_args([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad, rope_table=p["rope"], rope_cols=2 * A.inner,
+                                 rope_pos_offset=0, rows_per_batch=N, **nc)
+
+        def attn_args(A, s):
+            qkv, ao = p[f"qkv_{s}"], p[f"ao_{s}"]
+            es, base, aw = qkv.element_size(), qkv.data_ptr(), ao.stride(-2)
+            return L.attention_args(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
+                                    strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, aw, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * aw),
+                                    B=Bt, H=A.heads, Nq=N, Nk=N, kv_len=lens, q_len=zq, scale=scale, softclamp=self.softclamp, dtype=self.adc)
+
+        for i, ly in enumerate(W.layers):
+            last = i == c.depth - 1
+            nxt = None if last else W.layers[i + 1]
+            xn = p["skips"][i] if i < half else xo
+            ax, at_, af_ = self._opnd(xc), self._opnd(tc_), self._opnd(fc_)
+            fused = fz and i >= half
+            # ---- cross condition (x3:686-702): the three GEMMs read the PRE-update x, text, frames of this layer
+            G = []
+            if fused:
+                wd = p["wide"][c.depth - 1 - i]
+                ax = wd[..., :D]
+                G.append(self._mm_args([(wd, 2 * D, 2 * D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_skip"], p["xS"], M=rows, N=D, ldo=D))
+            else:
+                G.append(self._mm_args([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D, epilogue=L.EPI_RESID, resid=xc,
+                                       ldo=D, ldr=D, out_bf16=self._sh(xn)))
+            if not last:
+                ax_ld = ax.stride(-2)
+                G.append(self._mm_args([(ax, ax_ld, D), (at_, Dt, Dt)], ly["x_at"], tbuf[0], M=rows, N=Dt, epilogue=L.EPI_RESID, resid=tc_, ldo=Dt, ldr=Dt))
+                G.append(self._mm_args([(ax, ax_ld, D), (af_, Df, Df)], ly["x_af"], fbuf[0], M=rows, N=Df, epilogue=L.EPI_RESID, resid=fc_, ldo=Df, ldr=Df))
+            launch(G, "cross", "x_tfa")
+            if i < half:
+                src = xn
+            else:
+                src = p["xS"]
+                if not fused:       # (bf16 mode without the fused weights: skip_proj(cat(x, skip)) as its own launch)
+                    sk = self._opnd(p["skips"][c.depth - 1 - i])
+                    self._mm([(self._opnd(xn), D, D), (sk, sk.stride(-2), D)], ly["skip"], src, M=rows, N=D, ldo=D, **self._main_hint("skip"))
+            x = xo
+            # ---- position-generating convolutions, each with the RMSNorm after it folded in (x3:1082-1083, 1097-1098, 1122-1126)
+            n0 = self._nprod_ada(i, 0)
+            cv = ly["a_conv"]
+            convs = [dict(x=src, out=x, wt=cv.wt, bias=cv.b, d=D,
+                          norm=dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), gamma=n0["norm_gamma"], ssq=p["ssq_a"], step=n0.get("step"),
+                                    step_stride=n0.get("norm_step_stride", 0), batch_stride=n0.get("norm_batch_stride", 0)))]
+            if not last:
+                for s_, d_, buf in (("t", Dt, tbuf), ("f", Df, fbuf)):
+                    cvs = nxt[f"{s_}_conv"]
+                    hn = p[f"hn_{s_}"]
+                    convs.append(dict(x=buf[0], out=buf[1], wt=cvs.wt, bias=cvs.b, d=d_,
+                                      norm=dict(out_bf16=hn, ld_out_bf16=hn.stride(-2), gamma=nxt[f"{s_}_g1"], ssq=p[f"ssq_{s_}"])))
+            L.dwconv_grouped(convs, B=Bt, N=N, ksize=cv.k, lens=lens)
+            # ---- QKV projections (RoPE and the folded norm's 1 / rms in the epilogue), self-attention, out-projections
+            streams = [("a", D, ly["a_attn"], ly["a_ff"], x)]
+            if not last:
+                streams += [("t", Dt, nxt["t_attn"], nxt["t_ff"], tbuf[1]), ("f", Df, nxt["f_attn"], nxt["f_ff"], fbuf[1])]
+            launch([qkv_args(A, s_, d_, self._ncons(s_, d_)) for s_, d_, A, _, _ in streams], "qkv", "qkv")
+            L.attention_grouped([attn_args(A, s_) for s_, _, A, _, _ in streams])
+            r2 = nctx * N
+            n1 = self._nprod_ada(i, 1, switch_row=r2 if r2 < rows else 0) if nctx > 0 else self._nprod_ada(i, 2)
+            n1 = {k: v for k, v in n1.items() if k not in ("step", "rows_per_batch")}       # the gate already passes them
+            G = []
+            for s_, d_, A, _, xs in streams:
+                ao, hn = p[f"ao_{s_}"], p[f"hn_{s_}"]
+                if s_ == "a":
+                    kw = dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), out_bf16=hn, ld_out_bf16=hn.stride(-2), **n1)
+                else:
+                    kw = dict(epilogue=L.EPI_RESID, out_bf16=hn, ld_out_bf16=hn.stride(-2), norm_gamma=nxt[f"{s_}_g2"], norm_ssq=p[f"ssq_{s_}"])
+                G.append(self._mm_args([(ao, A.inner, A.inner)], A.w_out, xs, M=rows, N=d_, resid=xs, ldo=d_, ldr=d_, **kw))
+            launch(G, "out", "out")
+            # ---- the audio block's cross-attention to the T5 context (conditional half only; nothing to group it with)
+            if nctx > 0:
+                self._audio_cross_attention(i, ly, x, nctx, self._ncons("a", D), True, lens)
+            # ---- feed-forward (x3:817,884,917): GEGLU in, residual out
+            G = []
+            for s_, d_, _, Fw, _ in streams:
+                hn, ffh = p[f"hn_{s_}"], p[f"ffh_{s_}"]
+                G.append(self._mm_args([(hn, d_, d_)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, epilogue=L.EPI_GEGLU, bias=Fw.b1, ldo=ffh.stride(-2),
+                                       **self._ncons(s_, d_)))
+            launch(G, "ff1", "ff1")
+            G = []
+            for s_, d_, _, Fw, xs in streams:
+                ffh = p[f"ffh_{s_}"]
+                if s_ == "a":
+                    # the bf16 copy of this layer's output: into the wide buffer of the next layer's skip when that layer is fused;
+                    # after the last layer it is the operand of to_pred with the final RMSNorm folded in
+                    if last:
+                        kw = dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), norm_gamma=W.final_g, norm_ssq=p["ssq_a"])
+                    elif fz and half <= i + 1 < c.depth:
+                        sh = p["wide"][c.depth - 2 - i][..., :D]
+                        kw = dict(out_bf16=sh, ld_out_bf16=sh.stride(-2))
+                    else:
+                        kw = dict(out_bf16=self._sh(xs))
+                    kw.update(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2))
+                else:
+                    kw = dict(epilogue=L.EPI_RESID, out_bf16=self._sh(xs))
+                G.append(self._mm_args([(ffh, Fw.inner, Fw.inner)], Fw.w2, xs, M=rows, N=d_, bias=Fw.b2, resid=xs, ldo=d_, ldr=d_, **kw))
+            launch(G, "ff2", "ff2")
+            if not last:
+                tc_, fc_ = tbuf[1], fbuf[1]
+            xc, xo = xo, xc
+        # to_pred with the folded final norm (x3:1141-1143, 2083)
+        self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels, **self._ncons("a", D))
         return p["pred"]
 
     def euler_step(self, y, cfg_strength: float, remove_parallel_component: bool = False, keep_parallel_frac: float = 0.0):
