@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--main-tile", type=int, default=-1, help="A/B: GEMM tile configuration of the audio stream's narrow-output GEMMs (-1 library choice)")
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-grouped", action="store_true", help="A/B: the three-stream schedule of single launches instead of the chain of grouped launches")
+    ap.add_argument("--chains", default="", help="A/B: partition of the audio / text / frames streams into chains of grouped launches, e.g. 'atf' (one chain), "
+                    "'a|tf', 'af|t', 'a|t|f'")
     ap.add_argument("--group-tiles", default="", help="A/B: tile_hint per grouped launch, e.g. cross=13,qkv=7,out=13,ff1=7,ff2=13 (0 = by shape)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32 / bf16 32-step parity + throughput leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the supplementary configs[3] (V2P) and configs[4] (cascade) legs")
@@ -168,9 +170,12 @@ def main():
             table[(st_, op_)] = int(val)
     if args.no_grouped:
         model.engine().grouped = False
+    if args.chains:
+        model.engine().chains = tuple(tuple(ch) for ch in args.chains.split("|"))
     for item in filter(None, args.group_tiles.split(",")):
-        key, val = item.split("=")
-        model.engine().group_tiles[key] = int(val)
+        key, val = item.split("=")            # "ff1=7" for every group, "t+f.ff1=7" for the launches of one chain
+        tab = model.engine().group_tiles_split if args.dtype == "bf16x3" else model.engine().group_tiles
+        tab[tuple(key.split(".")) if "." in key else key] = int(val)
     if args.no_fold_norm:
         model.engine().fold_norm = False
     if args.no_fuse_skip:
@@ -285,7 +290,7 @@ def main():
                                % (3 if args.v2p else (4 if args.cascade > 1 else (1 if B == 1 else 2)), B, T, cfm_steps, evals, 2 * evals, NC,
                                   "V2P roll" if args.v2p else "V2A zero roll"),
                    "clips_per_gpu": B, "global_clips": n_clips, "parallelism": "clip-sharded x%d, 1 all-gather" % world,
-                   "hipgraph": not args.no_graph, "schedule": ("one chain of grouped launches" if model.engine()._use_grouped() else
+                   "hipgraph": not args.no_graph, "schedule": ("chains of grouped launches: " + " | ".join("+".join(ch) for ch in model.engine().chains) if model.engine()._use_grouped() else
                                                                ("single stream" if args.single_stream else "three streams")),
                    "side_streams": not args.single_stream and not model.engine()._use_grouped(), "cascade_passes": args.cascade},
         "per_gpu_mel_frames_per_s": round(frames_per_s / world, 2),

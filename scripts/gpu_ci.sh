@@ -41,6 +41,18 @@ for s in "$@"; do
     k8p) run k8p 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "8phase" ;;
     probe) TAILN=40 run probe 600 python scripts/gemm_probe.py ${PROBE_ARGS:-} ;;
     probe_geglu) TAILN=40 run probe_geglu 600 python scripts/gemm_probe.py --epi geglu 1564x8192x1024 1564x10240x1280 1564x4096x512 12512x8192x1024 ;;
+    gtiles) for v in ${GT_SWEEP:-"_" "qkv=13" "ff1=1" "ff2=15,out=15,cross=15" "_"}; do
+           a=""; [ "$v" != "_" ] && a="--group-tiles $v"
+           TAILN=0 run gt_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${GT_EXTRA:-}
+           echo "--- group tiles [$v] ${GT_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/gt_x.log | head -1)"
+         done ;;
+    chains) for v in ${CH_SWEEP:-"atf" "a|tf" "af|t" "a|t|f" "_"}; do
+           a="--chains $v"; [ "$v" = "_" ] && a="--no-grouped"
+           TAILN=0 run ch_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${CH_EXTRA:-}
+           echo "--- chains [$v] ${CH_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/ch_x.log | head -1)"
+         done ;;
+    gprobe) TAILN=60 run gprobe 600 python scripts/group_probe.py ${GP_ARGS:-} ;;
+    schedtests) TAILN=15 run schedtests 900 python -m pytest tests/test_grouped_gpu.py tests/test_sampler_gpu.py tests/test_full_shape_gpu.py -q -m gpu --tb=short -k "grouped" ;;
     grouped) TAILN=25 run grouped 600 python -m pytest tests/test_grouped_gpu.py -q -m gpu --tb=short ;;
     kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x --tb=short ;;
     kernels_all) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=line ;;

@@ -216,3 +216,111 @@ def test_dwconv_grouped_equals_separate(L, B, N, lens, norm):
         torch.cuda.synchronize()
         return outs
     _same(call(False), call(True))
+
+
+# ------------------------------------------------------------------------------------------- bf16x3 mode (split operands)
+def _planes(x32):
+    hi = x32.to(torch.bfloat16)
+    lo = (x32 - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], -1).contiguous()
+
+
+@pytest.mark.parametrize("tile_hint", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("family", ["resid", "store_rope", "geglu"])
+def test_gemm_grouped_split_operands(L, family, tile_hint):
+    """The bf16x3 mode's groups: A rows and W rows as hi | lo planes, three MFMA products per fp32 product; STORE to fp32 with RoPE (the
+    [q | k | v | gate] rows stay fp32 there), GEGLU to hi | lo planes, the fp32 residual family with split shadows.  The tile shape is
+    named (1..4 = the split ring tiles, 5 = the 8-phase kernel on three K segments): the ring sums hi*lo + lo*hi + hi*hi per K step, the
+    8-phase form sums the three products over all of K one after another -- same value up to fp32 rounding, not bit for bit, so a group
+    is compared with single launches of the SAME form."""
+    if family == "resid" and tile_hint == 5:
+        pytest.skip("the 8-phase form takes one logical K segment per problem")
+    M, rpb = 782, 391
+    ang = torch.arange(rpb + 4).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)))[None]
+    tab = torch.stack((ang.cos(), ang.sin()), -1).contiguous().to(DEV)
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)
+    probs = []
+    for j, (d, H) in enumerate(STREAMS):
+        g = _g(700 + j)
+        if family == "resid":
+            ks = [(d,), (d, 512), (256, d)][j]
+            N = d
+        elif family == "store_rope":
+            ks, N = (d,), 3 * H * 64 + 16
+        else:
+            ks, N = (d,), 8 * d if tile_hint in (5, 3) else 2 * d
+        a = [(_planes(torch.randn(M, k, generator=g) * 0.5).to(DEV), 2 * k, k) for k in ks]
+        K = sum(ks)
+        w = _planes(torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+        kw = dict(M=M, N=N, compute=L.BF16, a_split=True, bias=_f32(N, seed=720 + j))
+        if family == "resid":
+            resid = _f32(M, N, seed=730 + j)
+            if j == 0:
+                gate = torch.rand(3, N, generator=g).to(DEV)
+                kw.update(epilogue=L.EPI_GATE_RESID, resid=resid, gate=gate[0], step=step, gate_step_stride=N, rows_per_batch=rpb)
+            elif j == 1:
+                kw.update(epilogue=L.EPI_RESID, resid=resid)
+        elif family == "store_rope":
+            kw.update(rope_table=tab, rope_cols=2 * H * 64, rope_pos_offset=1, rows_per_batch=rpb)
+        else:
+            kw.update(epilogue=L.EPI_GEGLU, out_split=True)
+        probs.append((a, w, kw, family == "resid" and j < 2))
+
+    def call(grouped):
+        outs, built = [], []
+        for a, w, kw, shadow in probs:
+            N = kw["N"]
+            if family == "geglu":
+                out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)            # hi | lo planes of the N / 2 hidden values
+                extra = dict(ldo=N)
+            else:
+                out = torch.full((M, N), float("nan"), device=DEV)
+                extra = {}
+            if kw.get("resid") is not None:
+                out.copy_(kw["resid"])
+                kw = dict(kw, resid=out)
+            sh = None
+            if shadow:
+                sh = torch.zeros(M, 2 * N, dtype=torch.bfloat16, device=DEV)
+                extra.update(out_bf16=sh, ld_out_bf16=2 * N, out_bf16_split=True)
+            outs.append((out, sh, None))
+            if grouped:
+                built.append(L.gemm_args(a, w, out, **kw, **extra))
+            else:
+                L.gemm(a, w, out, tile_hint=tile_hint, **kw, **extra)
+        if grouped:
+            L.gemm_grouped(built, tile_hint=tile_hint)
+        torch.cuda.synchronize()
+        return outs
+    x, y = call(False), call(True)
+    for (o1, s1, _), (o2, s2, _) in zip(x, y):
+        assert torch.isfinite(o1.float()).all() and torch.equal(o1, o2), float((o1.float() - o2.float()).abs().max())
+        if s1 is not None:
+            assert torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("B,N,kv_len", [(2, 782, [782, 611]), (3, 100, [100, 64, 1])])
+def test_attention_grouped_split_equals_separate(L, B, N, kv_len):
+    """bf16x3 mode: fp32 q | k | v | gate buffers, split-bf16 MFMA products, hi | lo output planes."""
+    lens = torch.tensor(kv_len, dtype=torch.int32, device=DEV)
+    bufs = [(_f32(B * N, 3 * H * 64 + 16, seed=800 + j), H * 64, 3 * H * 64 + 16, H) for j, (_, H) in enumerate(STREAMS)]
+
+    def call(grouped):
+        outs, built = [], []
+        for qkv, inner, npad, H in bufs:
+            ao = torch.zeros(B * N, 2 * inner, dtype=torch.bfloat16, device=DEV)
+            base = qkv.data_ptr()
+            kw = dict(strides=(npad, npad, npad, npad, 2 * inner, N * npad, N * npad, N * npad, N * npad, N * 2 * inner), B=B, H=H, Nq=N, Nk=N,
+                      kv_len=lens, q_len=lens, scale=0.125, softclamp=50.0, dtype=L.BF16_SPLIT, out_split=True)
+            args = (base, base + inner * 4, base + 2 * inner * 4, base + 3 * inner * 4, ao.data_ptr())
+            if grouped:
+                built.append(L.attention_args(*args, **kw))
+            else:
+                L.attention(*args, **kw)
+            outs.append(ao)
+        if grouped:
+            L.attention_grouped(built)
+        torch.cuda.synchronize()
+        return outs
+    for a, b in zip(call(False), call(True)):
+        assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0 and torch.equal(a, b)

@@ -575,6 +575,33 @@ int dispatch_grouped(v2a_detail::GemmGroup& g, int epi, hipStream_t s) {
   return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped: epilogue %d on this tile shape", epi);
 }
 
+// split-bf16 operands (bf16x3 mode): STORE to fp32 (the [q | k | v | gate] rows stay fp32 there), GEGLU to hi | lo planes, fp32 residual family
+template <int BM, int BN, int WGM, int WGN, int NST>
+int dispatch_grouped_s3(v2a_detail::GemmGroup& g, int epi, hipStream_t s) {
+  switch (epi) {
+    case V2A_EPI_STORE: return launch_dma_grouped<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST, true>(g, s);
+    case V2A_EPI_GEGLU:
+      if constexpr ((BN / WGN / 16) % 2 == 0) return launch_dma_grouped<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST, true>(g, s);
+      break;
+    case V2A_EPI_GATE_RESID: return launch_dma_grouped<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST, true>(g, s);
+  }
+  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped(split bf16): epilogue %d on this tile shape", epi);
+}
+
+// split operands on the 8-phase kernel: three K segments [A_hi | A_hi | A_lo] against the weight row [W_hi | W_lo], the third segment
+// reading W_hi again (GemmParams::w_adj2)
+void split_as_three_segments(GemmParams& q) {
+  const int64_t k1 = q.kend[0];
+  const void* a0 = q.a[0];
+  q.nseg = 3;
+  q.a[0] = q.a[1] = a0;
+  q.a[2] = reinterpret_cast<const bf16_t*>(a0) + k1;
+  q.lda[1] = q.lda[2] = q.lda[0];
+  q.kend[0] = (int32_t)k1; q.kend[1] = (int32_t)(2 * k1); q.kend[2] = (int32_t)(3 * k1);
+  q.K = (int32_t)(3 * k1);
+  q.w_adj2 = -4 * k1;
+}
+
 }  // namespace
 
 // defaults: phase-interleaved 256x256 kernel for wide outputs once a launch has >= 400 tiles, i.e. from two clips per GPU on
@@ -795,13 +822,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     if (wide8) {
       GemmParams q = p;
       const int64_t k1 = a->ka[0];
-      q.nseg = 3;
-      q.a[0] = q.a[1] = a->a[0];
-      q.a[2] = reinterpret_cast<const bf16_t*>(a->a[0]) + k1;
-      q.lda[0] = q.lda[1] = q.lda[2] = a->lda[0];
-      q.kend[0] = (int32_t)k1; q.kend[1] = (int32_t)(2 * k1); q.kend[2] = (int32_t)(3 * k1);
-      q.K = (int32_t)(3 * k1);
-      q.w_adj2 = -4 * k1;        // bytes: segment 2 reads W_hi again
+      split_as_three_segments(q);
 #ifdef V2A_GEMM_PROBE
       if (tune.dbg & 32) { q.nseg = 1; q.K = (int32_t)k1; }      // error attribution: hi x hi only
 #endif
@@ -896,11 +917,13 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
 extern "C" int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_stream_t stream) {
   V2A_REQUIRE(args != nullptr && nprob >= 1 && nprob <= v2a_detail::kGroupMax, "v2a_gemm_grouped: %d problems (1..%d)", nprob, v2a_detail::kGroupMax);
   if (nprob == 1) return v2a_gemm(args, stream);
-  // the epilogue of the group: all STORE to bf16 (+ RoPE), all GEGLU to bf16, or fp32 results with any mix of STORE / RESID / GATE_RESID
-  const int e0 = args[0].epilogue;
-  const bool resid_family = e0 == V2A_EPI_RESID || e0 == V2A_EPI_GATE_RESID || (e0 == V2A_EPI_STORE && args[0].out_dtype == V2A_F32);
-  const int epi = resid_family ? V2A_EPI_GATE_RESID : e0;
-  V2A_REQUIRE(epi == V2A_EPI_STORE || epi == V2A_EPI_GEGLU || epi == V2A_EPI_GATE_RESID, "v2a_gemm_grouped: epilogue %d", e0);
+  // the epilogue of the group: fp32 results with any mix of STORE / RESID / GATE_RESID (one instantiation: absent operands read as 0 / 1),
+  // or one epilogue and output dtype for all -- STORE (bf16; split operands: fp32) with RoPE, or GEGLU (bf16; split operands: hi | lo planes)
+  bool any_resid = false;
+  for (int j = 0; j < nprob; ++j) any_resid = any_resid || args[j].epilogue == V2A_EPI_RESID || args[j].epilogue == V2A_EPI_GATE_RESID;
+  const bool split = args[0].a_dtype == V2A_BF16_SPLIT;
+  const int epi = any_resid ? V2A_EPI_GATE_RESID : args[0].epilogue;
+  V2A_REQUIRE(epi == V2A_EPI_STORE || epi == V2A_EPI_GEGLU || epi == V2A_EPI_GATE_RESID, "v2a_gemm_grouped: epilogue %d", args[0].epilogue);
   v2a_detail::GemmGroup g{};
   g.nprob = nprob;
   int order[v2a_detail::kGroupMax];
@@ -908,17 +931,19 @@ extern "C" int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_st
   for (int j = 0; j < nprob; ++j) {
     const v2a_gemm_args* a = args + j;
     if (int rc = gemm_prepare(a, tmp[j])) return rc;
-    V2A_REQUIRE(a->compute_dtype == V2A_BF16 && a->a_dtype == V2A_BF16 && tmp[j].vec_epi && !a->a_row_offset && !a->out_row_offset && !a->relu &&
-                    !(a->xcd_mask && (a->xcd_mask & 0xFF) != 0xFF),
-                "v2a_gemm_grouped: problem %d must be bf16 x bf16 with dense rows and 16-byte aligned epilogue operands", j);
-    if (resid_family)
+    V2A_REQUIRE(a->compute_dtype == V2A_BF16 && a->a_dtype == (split ? V2A_BF16_SPLIT : V2A_BF16) && tmp[j].vec_epi && !a->a_row_offset && !a->out_row_offset &&
+                    !a->relu && !(a->xcd_mask && (a->xcd_mask & 0xFF) != 0xFF),
+                "v2a_gemm_grouped: problem %d must be bf16 x bf16 (all plain or all split operands) with dense rows and 16-byte aligned epilogue operands", j);
+    if (any_resid) {
       V2A_REQUIRE(a->out_dtype == V2A_F32 && (a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID || a->epilogue == V2A_EPI_STORE) && !a->rope_table,
                   "v2a_gemm_grouped: problem %d: fp32 STORE / RESID / GATE_RESID problems group together (epilogue %d)", j, a->epilogue);
-    else
-      V2A_REQUIRE(a->epilogue == epi && a->out_dtype == V2A_BF16, "v2a_gemm_grouped: problem %d: epilogue %d / out dtype %d differs from the group's", j,
-                  a->epilogue, a->out_dtype);
-    if (resid_family && a->epilogue == V2A_EPI_STORE) tmp[j].resid = nullptr;
-    if (resid_family && a->epilogue != V2A_EPI_GATE_RESID) tmp[j].gate = nullptr;
+      if (a->epilogue == V2A_EPI_STORE) tmp[j].resid = nullptr;
+      if (a->epilogue != V2A_EPI_GATE_RESID) tmp[j].gate = nullptr;
+    } else {
+      const int want = epi == V2A_EPI_STORE ? (split ? V2A_F32 : V2A_BF16) : (split ? V2A_BF16_SPLIT : V2A_BF16);
+      V2A_REQUIRE(a->epilogue == epi && a->out_dtype == want, "v2a_gemm_grouped: problem %d: epilogue %d / out dtype %d differs from the group's (%d / %d)", j,
+                  a->epilogue, a->out_dtype, epi, want);
+    }
     V2A_REQUIRE(a->tile_hint == args[0].tile_hint, "v2a_gemm_grouped: one tile_hint for the whole group");
     order[j] = j;
   }
@@ -927,6 +952,36 @@ extern "C" int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_st
     for (int j = i; j > 0 && tmp[order[j]].K > tmp[order[j - 1]].K; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
   for (int j = 0; j < nprob; ++j) g.p[j] = tmp[order[j]];
   hipStream_t s = (hipStream_t)stream;
+  if (split) {
+    // split-operand tile shapes as for v2a_gemm: 1 = 64x64, 2 = 128x64, 3 = 128x128 (8 waves, 2-deep ring), 4 = 64x128 (8 waves), 5 = the
+    // 8-phase kernel on three K segments (one logical segment per problem); 0 = by shape
+    int cfg = args[0].tile_hint;
+    V2A_REQUIRE(cfg >= 0 && cfg <= 5, "v2a_gemm_grouped: tile_hint %d with split operands (0 = by shape, 1..5)", cfg);
+    if (cfg == 0) {
+      int64_t t256 = 0;
+      int nmax = 0;
+      bool one_seg = true;
+      for (int j = 0; j < nprob; ++j) {
+        t256 += (int64_t)((g.p[j].M + 255) / 256) * ((g.p[j].N + 255) / 256);
+        nmax = g.p[j].N > nmax ? g.p[j].N : nmax;
+        one_seg = one_seg && g.p[j].nseg == 1;
+      }
+      cfg = (one_seg && nmax >= 2048 && t256 >= 150 && v2a_detail::g_gemm_tuning.use_8phase) ? 5 : 4;
+    }
+    if (cfg == 5) {
+      for (int j = 0; j < nprob; ++j) {
+        V2A_REQUIRE(g.p[j].nseg == 1, "v2a_gemm_grouped: tile_hint 5 (8-phase) with split operands needs one segment per problem");
+        split_as_three_segments(g.p[j]);
+      }
+      return v2a_detail::launch_gemm_8phase_grouped(g, epi, epi == V2A_EPI_GEGLU ? V2A_BF16 : V2A_F32, s);
+    }
+    switch (cfg) {
+      case 1: return dispatch_grouped_s3<64, 64, 2, 2, 3>(g, epi, s);
+      case 2: return dispatch_grouped_s3<128, 64, 2, 2, 3>(g, epi, s);
+      case 3: return dispatch_grouped_s3<128, 128, 2, 4, 2>(g, epi, s);
+      default: return dispatch_grouped_s3<64, 128, 2, 4, 3>(g, epi, s);
+    }
+  }
   // tile shape: tile_hint k + 1 = configuration k as for v2a_gemm (7 = the 256x256 8-phase kernel); 0 = by the widest output of the group
   int cfg = args[0].tile_hint - 1;
   if (cfg < 0) {

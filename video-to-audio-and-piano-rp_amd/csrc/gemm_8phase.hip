@@ -287,8 +287,7 @@ int launch_8ph_grouped(v2a_detail::GemmGroup& g, hipStream_t s) {
 int v2a_detail::launch_gemm_8phase_grouped(GemmGroup& g, int epilogue, int out_dtype, hipStream_t s) {
   switch (epilogue) {
     case V2A_EPI_STORE:
-      if (out_dtype == V2A_BF16) return launch_8ph_grouped<V2A_EPI_STORE, bf16_t>(g, s);
-      break;
+      return out_dtype == V2A_BF16 ? launch_8ph_grouped<V2A_EPI_STORE, bf16_t>(g, s) : launch_8ph_grouped<V2A_EPI_STORE, float>(g, s);
     case V2A_EPI_GEGLU:
       if (out_dtype == V2A_BF16) return launch_8ph_grouped<V2A_EPI_GEGLU, bf16_t>(g, s);
       break;
