@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered, 2 lock-step)")
     ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
     ap.add_argument("--gemm-force-tile", type=int, default=-1, help="v2a_set_tuning: one tile configuration for every bf16 GEMM (experiment)")
+    ap.add_argument("--no-persistent", action="store_true", help="A/B: 8-phase GEMM kernel with one workgroup per tile (no cross-tile prefetch)")
     ap.add_argument("--xcd-1x8", action="store_true", help="A/B: round-1 XCD tile order (column strips) instead of the per-shape rectangle grid")
     ap.add_argument("--interleave-capture", type=int, default=-1, help="A/B: 1 = interleave the capture order of audio and side blocks")
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
@@ -107,6 +108,7 @@ def main():
     ap.add_argument("--main-tile", type=int, default=-1, help="A/B: GEMM tile configuration of the audio stream's narrow-output GEMMs (-1 library choice)")
     ap.add_argument("--side-tile", type=int, default=-2, help="A/B: GEMM tile configuration of the text / frames blocks (-1 library choice, default = engine's)")
     ap.add_argument("--no-grouped", action="store_true", help="A/B: the three-stream schedule of single launches instead of the chain of grouped launches")
+    ap.add_argument("--fold-all-regimes", action="store_true", help="A/B: fold the RMSNorms into GEMM epilogues (which the grouped chains need) at every batch size")
     ap.add_argument("--chains", default="", help="A/B: partition of the audio / text / frames streams into chains of grouped launches, e.g. 'atf' (one chain), "
                     "'a|tf', 'af|t', 'a|t|f'")
     ap.add_argument("--group-tiles", default="", help="A/B: tile_hint per grouped launch, e.g. cross=13,qkv=7,out=13,ff1=7,ff2=13 (0 = by shape)")
@@ -138,10 +140,10 @@ def main():
     from v2a_amd import _lib as L
     from v2a_amd.synth import random_state_dict, synthetic_conditioning
 
-    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8 or args.gemm_8phase_min_tiles > 0 or args.attn_one_group_from > 0:
+    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8 or args.gemm_8phase_min_tiles > 0 or args.attn_one_group_from > 0 or args.no_persistent:
         L.set_tuning(force_tile=args.gemm_force_tile, eight_phase=(args.gemm_8phase if args.gemm_8phase >= 0 else None),
                      eight_phase_min_tiles=args.gemm_8phase_min_tiles, xcd_order_1x8=args.xcd_1x8,
-                     attn_one_group_from=args.attn_one_group_from)
+                     attn_one_group_from=args.attn_one_group_from, persistent_8phase=not args.no_persistent)
     cfg = v2a_amd.DiTConfig()
     if args.clips_per_gpu <= 0:
         args.clips_per_gpu = 1 if world == 1 else 8
@@ -170,6 +172,8 @@ def main():
             table[(st_, op_)] = int(val)
     if args.no_grouped:
         model.engine().grouped = False
+    if args.fold_all_regimes:
+        model.engine().fold_all_regimes = True
     if args.chains:
         model.engine().chains = tuple(tuple(ch) for ch in args.chains.split("|"))
     for item in filter(None, args.group_tiles.split(",")):

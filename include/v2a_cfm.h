@@ -178,7 +178,8 @@ typedef struct v2a_tuning {
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t attn_one_group_from;    /* v2a_attention (bf16): launches with at least this many workgroups run one wave group per workgroup
                                    * instead of two that split the key tiles (0 = default 1536) */
-  int32_t reserved[1];
+  int32_t reserved[1];            /* bit 6 (64): the 8-phase kernel with one workgroup per tile instead of persistent workgroups that prefetch
+                                   * their next tile's first K tile behind the epilogue (A/B); other bits: probe builds only */
 } v2a_tuning;
 int v2a_set_tuning(const v2a_tuning* tuning);
 

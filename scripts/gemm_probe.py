@@ -21,7 +21,9 @@ SAMPLER_SHAPES = ["1564x3088x1024", "1564x3088x1280", "1564x1552x512", "1564x819
 
 
 def set_cfg(t):
-    if t == 6:
+    if t == 26:                         # the 8-phase kernel with one workgroup per tile (no persistent workgroups / cross-tile prefetch)
+        _lib.set_tuning(force_tile=6, eight_phase=1, persistent_8phase=False)
+    elif t == 6:
         _lib.set_tuning(force_tile=6, eight_phase=1)
     elif t == 7:
         _lib.set_tuning(force_tile=6, eight_phase=2)

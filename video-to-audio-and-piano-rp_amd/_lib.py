@@ -171,14 +171,15 @@ def lib():
 
 
 def set_tuning(force_tile: int = -1, k_rotation: bool = False, eight_phase: int | None = None, eight_phase_min_tiles: int = 0,
-               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0):
-    """Tile-selection overrides (A/B measurements); `set_tuning()` restores the library defaults."""
+               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0, persistent_8phase: bool = True):
+    """Tile-selection overrides (A/B measurements); `set_tuning()` restores the library defaults.
+    persistent_8phase=False: the 8-phase GEMM kernel with one workgroup per tile (no cross-tile prefetch), as before round 4."""
     if (force_tile == -1 and not k_rotation and eight_phase is None and eight_phase_min_tiles == 0 and dwconv_rows_per_wave == 0
-            and not xcd_order_1x8 and attn_one_group_from == 0):
+            and not xcd_order_1x8 and attn_one_group_from == 0 and persistent_8phase):
         check(lib().v2a_set_tuning(None))
         return
     t = Tuning(force_tile, 1 if k_rotation else 0, 1 if eight_phase is None else eight_phase, eight_phase_min_tiles, dwconv_rows_per_wave,
-               1 if xcd_order_1x8 else 0, attn_one_group_from)
+               1 if xcd_order_1x8 else 0, attn_one_group_from, (C.c_int32 * 1)(0 if persistent_8phase else 64))
     check(lib().v2a_set_tuning(C.byref(t)))
 
 

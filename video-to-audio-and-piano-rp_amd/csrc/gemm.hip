@@ -552,6 +552,7 @@ int launch_dma_grouped(v2a_detail::GemmGroup& g, hipStream_t s) {
     total += (g.p[j].tiles_m * g.p[j].tiles_n + 7) / 8 * 8;
   }
   for (int j = g.nprob; j <= v2a_detail::kGroupMax; ++j) g.start[j] = 0x7fffffff;
+  g.total = total;
   constexpr size_t smem = NST * (size_t)(BM + BN) * 128 * (S3 ? 2 : 1) + BM * 4 + 16;
   static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
   auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3, true>;
@@ -613,6 +614,7 @@ v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 int v2a_detail::g_attn_one_group_from = 1536;
 int v2a_detail::g_probe_dbg = 0;       // v2a_tuning.reserved[0]: read by probe builds only
+int v2a_detail::g_8ph_persistent = 1;   // v2a_tuning.reserved[0] bit 6 switches it off (A/B)
 int v2a_detail::g_dwconv_stream = 1;   // streaming depthwise conv for chip-filling launches (dwconv_rows_per_wave = -1 switches it off: A/B)
 
 extern "C" int v2a_gemm_args_size(void) { return (int)sizeof(v2a_gemm_args); }
@@ -624,6 +626,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
     v2a_detail::g_dwconv_stream = 1;
     v2a_detail::g_attn_one_group_from = 1536;
     v2a_detail::g_probe_dbg = 0;
+    v2a_detail::g_8ph_persistent = 1;
     return V2A_OK;
   }
   // every field is checked before any is assigned: a rejected call leaves the previous tuning whole
@@ -639,6 +642,7 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
                                t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,
                                t->gemm_xcd_order_1x8 ? 0 : 1, t->reserved[0]};
   v2a_detail::g_probe_dbg = t->reserved[0];
+  v2a_detail::g_8ph_persistent = (t->reserved[0] & 64) ? 0 : 1;
   return V2A_OK;
 }
 
@@ -991,7 +995,9 @@ extern "C" int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_st
       t256 += (int64_t)((g.p[j].M + 255) / 256) * ((g.p[j].N + 255) / 256);
       nmax = g.p[j].N > nmax ? g.p[j].N : nmax;
     }
-    cfg = (nmax >= 2048 && t256 >= 150 && v2a_detail::g_gemm_tuning.use_8phase) ? 6 : 12;
+    // wide outputs with enough 256x256 tiles for a round, and anything that fills the chip several times over: the 8-phase kernel
+    // (v2a_gemm's own thresholds, applied to the group's tile count); launches that cannot fill the chip: 128x128 with eight waves
+    cfg = (v2a_detail::g_gemm_tuning.use_8phase && ((nmax >= 2048 && t256 >= 150) || (nmax > 512 && t256 >= 400))) ? 6 : (t256 >= 400 ? 0 : 12);
   }
   switch (cfg) {
     case 6: return v2a_detail::launch_gemm_8phase_grouped(g, epi, epi == V2A_EPI_GATE_RESID ? V2A_F32 : V2A_BF16, s);

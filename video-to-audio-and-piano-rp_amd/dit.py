@@ -268,12 +268,17 @@ class DiTEngine:
         # workgroups fill the chip together -- no cross-stream hand-offs, no kernels queueing behind another stream's fat workgroups
         # (the three-stream schedule ran every kernel ~1.5x its stand-alone time: profiles/r03_timeline_multistream.txt).
         self.grouped = True
+        self.fold_all_regimes = False       # experiment: RMSNorms folded into GEMM epilogues (and thus grouped chains) at every batch size
         # how the three streams are cut into chains of grouped launches (forward_grouped): one chain, audio | text + frames,
         # audio + frames | text, or three chains of single launches
         self.chains = (("a", "t", "f"),)
         # tile_hint of each grouped launch (cfg + 1 of v2a_gemm's tile configurations; 7 = the 256x256 8-phase kernel, 13 = 128x128 with
         # eight waves): measured per group with `bench.py --group-tiles` (profiles/r04_group_tiles.txt)
-        self.group_tiles = {"cross": 13, "qkv": 7, "out": 13, "ff1": 7, "ff2": 13}
+        # keys: op for every chain, or ("a+f", op) for the launches of one chain; stand-alone times of every group and tile shape:
+        # scripts/group_probe.py, profiles/r04_group_probe.txt (64x128 / 8 waves = 16 is the best narrow tile for two-problem groups)
+        self.group_tiles = {"cross": 13, "qkv": 16, "out": 16, "ff1": 7, "ff2": 13,
+                            ("a+f", "cross"): 15, ("a+f", "qkv"): 16, ("a+f", "out"): 16, ("a+f", "ff1"): 16, ("a+f", "ff2"): 15,
+                            ("t+f", "cross"): 16, ("t+f", "qkv"): 16, ("t+f", "out"): 16, ("t+f", "ff1"): 1, ("t+f", "ff2"): 16}
         # ... of the bf16x3 mode's groups (split operands have their own tile numbering, v2a_gemm_grouped: 1 = 64x64, 2 = 128x64,
         # 3 = 128x128 / 8 waves, 4 = 64x128 / 8 waves, 5 = the 8-phase kernel on three K segments; 0 = by shape)
         self.group_tiles_split = {"cross": 0, "qkv": 0, "out": 0, "ff1": 5, "ff2": 0}
@@ -399,7 +404,7 @@ class DiTEngine:
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
                 tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
-                self.grouped, tuple(self.chains), tuple(sorted(self.group_tiles.items(), key=str)), tuple(sorted(self.group_tiles_split.items(), key=str)), self.interleave_capture, self.rope_cross, self.zero_masked_queries)
+                self.grouped, self.fold_all_regimes, tuple(self.chains), tuple(sorted(self.group_tiles.items(), key=str)), tuple(sorted(self.group_tiles_split.items(), key=str)), self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
     def _sh(self, buf):
@@ -478,7 +483,7 @@ class DiTEngine:
         """... into a GEMM epilogue only up to two clips: the extra bf16 row pieces cost an out-projection launch 2 us of 24 at
         one clip (a norm launch: 7.7 us) but 20-26 us of 58 at 8 clips per GPU, more than the 16.5 us norm launch they replace
         (the conv fold wins at every size: 46 us against 49 + 16.5)."""
-        return self._fold() and self._regime() < 2
+        return self._fold() and (self._regime() < 2 or self.fold_all_regimes)
 
     def _nprod_ada(self, layer, slot, switch_row=0):
         """Producer side of a folded AdaptiveRMSNorm (audio stream): kwargs for the RESID / GATE_RESID GEMM or the conv that
