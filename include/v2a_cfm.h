@@ -178,8 +178,10 @@ typedef struct v2a_tuning {
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t attn_one_group_from;    /* v2a_attention (bf16): launches with at least this many workgroups run one wave group per workgroup
                                    * instead of two that split the key tiles (0 = default 1536) */
-  int32_t reserved[1];            /* bit 6 (64): the 8-phase kernel with one workgroup per tile instead of persistent workgroups that prefetch
-                                   * their next tile's first K tile behind the epilogue (A/B); other bits: probe builds only */
+  int32_t reserved[1];            /* bit 6 (64): the 8-phase kernel with persistent workgroups (one per CU) that request their next tile's first K
+                                   * tile before the epilogue of the current one, instead of one workgroup per tile.  Off by default: +2.5 % per
+                                   * launch alone at 8 clips per GPU, -2.3 % in the sampler, where the static tile shares collide with the other
+                                   * streams' workgroups (profiles/r04_8phase_persistent_*.txt).  Other bits: probe builds only */
 } v2a_tuning;
 int v2a_set_tuning(const v2a_tuning* tuning);
 

@@ -51,6 +51,15 @@ for s in "$@"; do
            TAILN=0 run ch_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${CH_EXTRA:-}
            echo "--- chains [$v] ${CH_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/ch_x.log | head -1)"
          done ;;
+    x3qkv) for v in "_" "a.qkv=5,t.qkv=5" "a.qkv=5,t.qkv=5,f.qkv=5" "_"; do
+           a=""; [ "$v" != "_" ] && a="--side-tiles $v"
+           TAILN=0 run x3_x 300 python bench.py --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a
+           echo "--- bf16x3 split tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/x3_x.log | head -1)"
+         done ;;
+    persab) for v in "" "--persistent" "" "--persistent"; do
+           TAILN=0 run pa_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v ${PA_EXTRA:-}
+           echo "--- [$v] ${PA_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/pa_x.log | head -1) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/pa_x.log | head -1)"
+         done ;;
     gprobe) TAILN=60 run gprobe 600 python scripts/group_probe.py ${GP_ARGS:-} ;;
     schedtests) TAILN=15 run schedtests 900 python -m pytest tests/test_grouped_gpu.py tests/test_sampler_gpu.py tests/test_full_shape_gpu.py -q -m gpu --tb=short -k "grouped" ;;
     grouped) TAILN=25 run grouped 600 python -m pytest tests/test_grouped_gpu.py -q -m gpu --tb=short ;;

@@ -171,15 +171,15 @@ def lib():
 
 
 def set_tuning(force_tile: int = -1, k_rotation: bool = False, eight_phase: int | None = None, eight_phase_min_tiles: int = 0,
-               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0, persistent_8phase: bool = True):
+               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0, persistent_8phase: bool = False):
     """Tile-selection overrides (A/B measurements); `set_tuning()` restores the library defaults.
-    persistent_8phase=False: the 8-phase GEMM kernel with one workgroup per tile (no cross-tile prefetch), as before round 4."""
+    persistent_8phase=True: the 8-phase GEMM kernel with persistent workgroups and cross-tile prefetch (off by default, v2a_tuning.reserved)."""
     if (force_tile == -1 and not k_rotation and eight_phase is None and eight_phase_min_tiles == 0 and dwconv_rows_per_wave == 0
-            and not xcd_order_1x8 and attn_one_group_from == 0 and persistent_8phase):
+            and not xcd_order_1x8 and attn_one_group_from == 0 and not persistent_8phase):
         check(lib().v2a_set_tuning(None))
         return
     t = Tuning(force_tile, 1 if k_rotation else 0, 1 if eight_phase is None else eight_phase, eight_phase_min_tiles, dwconv_rows_per_wave,
-               1 if xcd_order_1x8 else 0, attn_one_group_from, (C.c_int32 * 1)(0 if persistent_8phase else 64))
+               1 if xcd_order_1x8 else 0, attn_one_group_from, (C.c_int32 * 1)(64 if persistent_8phase else 0))
     check(lib().v2a_set_tuning(C.byref(t)))
 
 
@@ -299,6 +299,13 @@ def gemm_grouped(built, tile_hint=0):
     """built: 1..3 results of gemm_args -- independent problems run as ONE launch (v2a_gemm_grouped): the same Linear of the audio,
     text and frames blocks of a layer.  tile_hint applies to the whole group (0 = by shape)."""
     n = len(built)
+    if n == 1:              # one problem = a plain v2a_gemm launch (and its profiler class)
+        g, key, flops, nbytes = built[0]
+        g.tile_hint = tile_hint if g.compute_dtype == BF16 and g.a_dtype in (BF16, BF16_SPLIT) and g.epilogue != EPI_SIGMOID else 0
+        if g.tile_hint:
+            key = key.replace(">", ",tile%d>" % (g.tile_hint - 1), 1) if ",tile" not in key else key
+        _launch(key, flops, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
+        return
     arr = (GemmArgs * n)()
     for i, (g, _, _, _) in enumerate(built):
         C.memmove(C.byref(arr[i]), C.byref(g), C.sizeof(GemmArgs))

@@ -255,7 +255,9 @@ class DiTEngine:
         self.side_tiles = {("t", "cross"): 12, ("t", "out"): 12, ("t", "ff2"): 12, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
                            ("f", "ff1"): 6, ("f", "qkv"): 6, ("f", "cross"): 12, ("f", "out"): 12, ("f", "ff2"): 12}
         self.main_tile = 14             # tile configuration of the audio stream's narrow-output GEMMs at one clip (-1 = library choice)
-        self.split_tiles = {}           # bf16x3 mode: (stream, op) -> split-operand tile shape 1..4 of v2a_gemm (default: by shape)
+        # bf16x3 mode: (stream, op) -> split-operand tile shape 1..5 of v2a_gemm (default: by shape).  Round 4: the audio / text QKV projections
+        # (N = 3088: 91 tiles of 256x256) on the 8-phase kernel's three-segment form instead of the 2-deep 128x128 split ring (90 us): +1 %
+        self.split_tiles = {("a", "qkv"): 5, ("t", "qkv"): 5}
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
@@ -271,7 +273,11 @@ class DiTEngine:
         self.fold_all_regimes = False       # experiment: RMSNorms folded into GEMM epilogues (and thus grouped chains) at every batch size
         # how the three streams are cut into chains of grouped launches (forward_grouped): one chain, audio | text + frames,
         # audio + frames | text, or three chains of single launches
-        self.chains = (("a", "t", "f"),)
+        # Measured (profiles/r04_chains_ab.txt, one clip, mel-frames/s): one chain 5282, a | t+f 5400, a+f | t 5630-5730, three chains 5790-5890
+        # = forward()'s three streams 5720-5870; 8 clips per GPU: one chain 8371 against 8833.  Lock-step grouped launches lose what three
+        # independent queues give for free: every kernel's tail round is filled by the other queues' workgroups, and latency-bound kernels
+        # (attention, convolutions) run beside bandwidth-bound ones.  Default: three chains (the schedule of forward(), on this scheduler).
+        self.chains = (("a",), ("t",), ("f",))
         # tile_hint of each grouped launch (cfg + 1 of v2a_gemm's tile configurations; 7 = the 256x256 8-phase kernel, 13 = 128x128 with
         # eight waves): measured per group with `bench.py --group-tiles` (profiles/r04_group_tiles.txt)
         # keys: op for every chain, or ("a+f", op) for the launches of one chain; stand-alone times of every group and tile shape:
