@@ -65,6 +65,7 @@ PEAK_HBM_GBS = 8000.0
 PMC_FILES = ("r03_pmc1_summary.csv", "r03_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
 ROCPROF_STATS = "r03_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
 ROCPROF_STATS_MULTI = "r03_kernel_stats_multistream.csv"         # ... of the production configuration (three streams)
+ROCPROF_STATS_8CLIPS = "r03_kernel_stats_8clips.csv"             # ... of `bench.py --clips-per-gpu 8`
 
 
 def main():
@@ -392,7 +393,7 @@ def summary_fields(res):
             for k, row in r8["kernels"].items():
                 if k.startswith("gemm<bf16") and "tflops" in row:
                     cls = k.split(",")[2]
-                    key = "qkv_store_bf16" if (cls == "store" and ",bf16," in k) else cls
+                    key = "qkv_store_bf16" if (cls == "store" and k.split(",")[3].startswith("bf16")) else cls
                     best = fr.get(key)
                     if best is None or row["share"] > best[1]:
                         fr[key] = (round(row["tflops"] / PEAK_BF16_TFLOPS, 4), row["share"])
@@ -402,7 +403,7 @@ def summary_fields(res):
                                         **{"clips8_frac_" + k: v[0] for k, v in fr.items()}})
     h8 = res.get("roofline", {}).get("hbm", {}).get("clips_8")
     if h8:
-        summ["hbm_clips_8"] = {k: v["frac"] for k, v in h8.items()}
+        summ["hbm_clips_8"] = {k: {"live": v["frac"], "rocprof": (v.get("rocprof") or {}).get("frac")} for k, v in h8.items()}
     if summ:
         out["summary"] = summ
     return out
@@ -649,6 +650,11 @@ def roofline_leg(model, L, args, production=False):
             gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             hbm[k] = {"launches_per_eval": a["launches"] // reps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
                       "MB_per_launch": round(a["bytes"] / a["launches"] / 1e6, 3), "achieved_GBs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            # the same kernel in the committed rocprofv3 summary of this shape: kernel-only duration, without the ~2 us of event packets
+            # the live figure includes (they are a quarter of a 10 us memory-bound launch)
+            rp = rocprof_hbm(k, a["bytes"] / a["launches"], ROCPROF_STATS_8CLIPS if model.engine().plan["B"] >= 8 else ROCPROF_STATS_MULTI)
+            if rp:
+                hbm[k]["rocprof"] = rp
 
     def table_of(ag):
         table, tot_ms = {}, sum(a["ms"] for a in ag.values())
@@ -763,18 +769,28 @@ def configs_leg(model, cfg, args, T, NC, dev):
 
 
 def _kernel_rows(fn, kernel_key, name_col):
-    """Rows of a committed rocprofv3 summary that belong to the LDS-DMA instantiation(s) of a bench kernel class."""
+    """Rows of a committed rocprofv3 summary that belong to the instantiation(s) of a bench GEMM class `gemm<bf16,a_bf16,EPI,OUT[,tileN]>`:
+    the LDS-DMA ring kernel, or the 256x256 8-phase kernel for `tile6`.  rocprofv3 prints these names demangled, half demangled (`__bf16`
+    comes out as `bool _Accum`) or mangled, depending on the instantiation."""
     import csv
     epi = {"store": "0", "sigmoid": "1", "geglu": "2", "resid": "3", "gate_resid": "4"}
-    parts = kernel_key[len("gemm<"):-1].split(",")
-    tag_e, tag_o = "Li%sE" % epi[parts[2]], ("DF16b" if parts[3] == "bf16" else "f")
+    parts = kernel_key[kernel_key.index("<") + 1:-1].split(",")
+    e, bf_out = epi[parts[2]], parts[3].startswith("bf16")
+    tiles = [x for x in parts[4:] if x.startswith("tile")]
+    bases = ("gemm_bf16_8ph_kernel",) if "tile6" in tiles else (("gemm_bf16_dma_kernel",) if tiles else ("gemm_bf16_dma_kernel", "gemm_bf16_8ph_kernel"))
     out = []
     for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
         k = r[name_col].replace("void ", "").replace("(anonymous namespace)::", "")
-        if "gemm_bf16_dma_kernel" not in k:
+        base = next((b_ for b_ in bases if b_ in k), None)
+        if base is None:
             continue
-        if (k.startswith("gemm_bf16_dma_kernel<%s, %s" % (epi[parts[2]], "float" if tag_o == "f" else "__bf16"))
-                or "gemm_bf16_dma_kernelI%s%s" % (tag_e, tag_o) in k or k.startswith("gemm_bf16_dma_kernel<%s%s" % (tag_e, tag_o))):
+        t = k[k.find(base) + len(base):]
+        if t.startswith("<"):                        # (half) demangled: <EPI, OutT, ...
+            f = [x.strip() for x in t[1:].split(",")]
+            ok = f[0] == e and ((f[1] in ("__bf16", "bool _Accum")) if bf_out else f[1] == "float")
+        else:                                        # mangled: ILi{EPI}E{f | DF16b}...
+            ok = t.startswith("ILi%sE%s" % (e, "DF16b" if bf_out else "f"))
+        if ok:
             out.append(r)
     return out
 
@@ -791,7 +807,32 @@ def rocprof_avg(kernel_key, flops_per_launch, peak, stats_file=None):
         us = float(best["AverageNs"]) / 1e3
         tf = flops_per_launch / (us * 1e-6) / 1e12
         return {"avg_us": round(us, 2), "calls": int(best["Calls"]), "achieved": round(tf, 2), "frac": round(tf / peak, 4),
-                "source": "profiles/%s (%s)" % (stats_file, best["Name"][:70])}
+                "source": "profiles/%s (%s)" % (stats_file, best["Name"].replace("void (anonymous namespace)::", "")[:70])}
+    except Exception:
+        return None
+
+
+_HBM_KERNELS = {"rmsnorm": ("rmsnorm_kernel",), "dwconv+norm": ("dwconv_kernel<31, 4, true>", "dwconv_stream_kernel<31, true", "dwconv_group_kernel<31, 4, true>"),
+                "dwconv": ("dwconv_kernel<31, 4, false>", "dwconv_kernel<31, 6, false>", "dwconv_stream_kernel<31, false"), "cfg_euler": ("cfg_euler_kernel",),
+                "linear_small": ("linear_small_kernel",), "rope": ("rope_kernel",)}
+
+
+def rocprof_hbm(key, bytes_per_launch, stats_file):
+    """A memory-bound kernel class of the bench in a committed `rocprofv3 --kernel-trace --stats` summary: calls, average kernel-only
+    duration, and the algorithmic bytes per launch over that duration against the 8 TB/s HBM peak."""
+    try:
+        import csv
+        names = next(v for k, v in _HBM_KERNELS.items() if key.split("<")[0] == k)
+        calls, ns = 0, 0.0
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", stats_file))):
+            if any(n in r["Name"] for n in names):
+                calls += int(r["Calls"])
+                ns += float(r["TotalDurationNs"])
+        if not calls:
+            return None
+        us = ns / calls / 1e3
+        gbs = bytes_per_launch / (us * 1e-6) / 1e9
+        return {"avg_us": round(us, 2), "calls": calls, "achieved_GBs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4), "source": "profiles/" + stats_file}
     except Exception:
         return None
 

@@ -20,7 +20,7 @@ def bench():
 
 
 def test_profile_files_named_by_bench_exist(bench):
-    for fn in (*bench.PMC_FILES, bench.ROCPROF_STATS, bench.ROCPROF_STATS_MULTI):
+    for fn in (*bench.PMC_FILES, bench.ROCPROF_STATS, bench.ROCPROF_STATS_MULTI, bench.ROCPROF_STATS_8CLIPS):
         assert os.path.isfile(os.path.join(ROOT, "profiles", fn)), fn
 
 
@@ -64,4 +64,10 @@ def test_summary_fields_pick_the_parity_qualified_mode(bench):
     assert pq["mode"] == "bf16x3" and pq["mel_frames_per_s"] == 2799.0 and pq["max_abs_delta_mel_over_grid"] < 1e-3 and "OUTSIDE" in pq["note"]
     assert out["n1_8clips_mel_frames_per_s"] == 8847.0
     assert list(out)[-1] == "summary" and out["summary"]["batched_8clips"]["frac_geglu"] == round(947.0 / 2500.0, 4)
-    assert res["roofline"]["clips8_frac_qkv_store_bf16"] == round(585.0 / 2500.0, 4) and out["summary"]["hbm_clips_8"] == {"rmsnorm": 0.495}
+    assert res["roofline"]["clips8_frac_qkv_store_bf16"] == round(585.0 / 2500.0, 4) and out["summary"]["hbm_clips_8"] == {"rmsnorm": {"live": 0.495, "rocprof": None}}
+
+
+def test_rocprof_hbm_block_finds_the_memory_bound_kernels(bench):
+    for key, mb in (("rmsnorm<bf16>", 100.0), ("dwconv+norm", 120.0), ("cfg_euler", 12.3)):
+        r = bench.rocprof_hbm(key, mb * 1e6, bench.ROCPROF_STATS_8CLIPS)
+        assert r is not None and r["calls"] > 10 and 1.0 < r["avg_us"] < 200.0, (key, r)

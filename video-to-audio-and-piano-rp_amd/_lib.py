@@ -413,6 +413,9 @@ def dwconv_grouped(probs, *, B, N, ksize, lens=None):
     """probs: 1..3 dicts(x, out, wt, bias, d, norm=None or the dict of dwconv()) -- the convolutions of the audio / text / frames blocks
     of a layer as one launch (v2a_dwconv_grouped)."""
     n = len(probs)
+    if n == 1:              # one problem = the plain launch (and its profiler class)
+        q = probs[0]
+        return dwconv(q["x"], q["out"], q["wt"], q["bias"], B=B, N=N, d=q["d"], ksize=ksize, lens=lens, norm=q.get("norm"))
     arr = (DwconvArgs * n)()
     for i, q in enumerate(probs):
         arr[i].x, arr[i].out, arr[i].wt, arr[i].bias, arr[i].d = q["x"].data_ptr(), q["out"].data_ptr(), q["wt"].data_ptr(), q["bias"].data_ptr(), q["d"]
@@ -452,6 +455,9 @@ def attention(q, k, v, gate, out, **kw):
 def attention_grouped(built):
     """built: 1..3 results of attention_args (bf16, same B / Nq / Nk / scale / softclamp): one launch over the heads of all of them."""
     n = len(built)
+    if n == 1:
+        a, key, flops, nbytes = built[0]
+        return _launch(key, flops, nbytes, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
     arr = (AttnArgs * n)()
     for i, (a, _, _, _) in enumerate(built):
         C.memmove(C.byref(arr[i]), C.byref(a), C.sizeof(AttnArgs))

@@ -205,6 +205,41 @@ class PackedWeights:
             ly["a_attn2"].wk = ly["a_attn2"].wv = None
 
 
+# ---- measured tile choices, in ONE place -----------------------------------------------------------------------------------------
+# key: (compute mode, regime, (dim, dim_text, dim_frames, ff_mult)); regime as DiTEngine._regime(): 0 = a launch cannot fill the chip (one
+# clip at these widths), 1 = about fills it (two clips), 2 = fills it several times over.  value: {(stream, op): (tile, log)} where
+# `tile` is a tile configuration of v2a_gemm (bf16: the k of tile_hint = k + 1; bf16x3: the split-operand shape 1..5 = tile_hint) and `log`
+# names the A/B record under profiles/ that justifies the entry.  streams a / t / f; ops: x_tfa skip qkv out q2 out2 ff1 ff2 (audio),
+# cross qkv out ff1 ff2 (text, frames).  A (mode, regime, widths) without a row, and an op without an entry, take the stream's policy
+# tile (DiTEngine.side_tile / main_tile: fat 128x256 tiles on the side streams, the library's choice on the audio stream) -- correct
+# everywhere, measured only where a row exists.  bench.py --side-tiles / --big-tiles / --main-tile override entries for A/B runs.
+SHIPPED_WIDTHS = (1024, 1280, 512, 4)
+_R2, _R3 = "profiles/r02 A/B runs (DESIGN.md appendix A, `scripts/gpu_ci.sh sidetiles`)", "profiles/r03_tile_sweep.txt"
+TUNED_TILES = {
+    ("bf16", 0, SHIPPED_WIDTHS): {
+        # text stream co-critical with the audio stream: its 1280-wide GEMMs on 128x128 tiles with eight waves (tile 12), feed-forward in on
+        # the 256x256 8-phase kernel (tile 6)
+        ("t", "cross"): (12, _R3), ("t", "out"): (12, _R3), ("t", "ff2"): (12, _R3), ("t", "ff1"): (6, _R2),
+        ("f", "cross"): (12, _R3), ("f", "out"): (12, _R3), ("f", "ff2"): (12, _R3), ("f", "ff1"): (6, _R2), ("f", "qkv"): (6, _R2),
+        # audio stream: narrow outputs on 128x64 tiles with eight waves (tile 14), QKV on 128x128 (tile 1), feed-forward in on the 8-phase kernel
+        ("a", "x_tfa"): (14, _R3), ("a", "skip"): (14, _R3), ("a", "out"): (14, _R3), ("a", "out2"): (14, _R3), ("a", "ff2"): (14, _R3),
+        ("a", "qkv"): (1, _R2), ("a", "ff1"): (6, _R2),
+    },
+    # two clips: the one-clip table costs 4 % here (6214 vs 6467 mel-frames/s, round 2): policy tiles only
+    ("bf16", 1, SHIPPED_WIDTHS): {},
+    # from three clips on every kernel fills the chip and the library's stand-alone choice wins: an 8-clip sweep of every entry measured <= 0
+    ("bf16", 2, SHIPPED_WIDTHS): {},
+    # bf16x3, one clip: QKV of the audio / text streams (N = 3088: 91 tiles of 256x256) on the 8-phase kernel's three-segment form instead
+    # of the 2-deep 128x128 split ring (90 us per launch): +1 %; everything else by shape (profiles/r03_split_gemm_probe.txt)
+    ("bf16x3", 0, SHIPPED_WIDTHS): {("a", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt"), ("t", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt")},
+}
+
+
+def tuned_tiles(mode: str, regime: int, widths) -> dict:
+    """{(stream, op): tile} of a measured (mode, regime, widths) row, {} when there is none."""
+    return {k: v[0] for k, v in TUNED_TILES.get((mode, regime, tuple(widths)), {}).items()}
+
+
 _STREAMS: dict = {}
 
 
@@ -246,41 +281,36 @@ class DiTEngine:
         # GEMM on the phase-interleaved kernel too (+2 %), its QKV GEMM on 128x128 tiles (+0.4 %); frames feed-forward on the
         # phase-interleaved kernel (+0.6 %), frames QKV too (49 tiles: +1.7 %).  Each entry A/B-ed alone and in combination on one box (bench.py --side-tiles).
         self.fuse_skip = True           # bf16 mode: cross-condition + skip projection of layers >= depth/2 as one GEMM (PackedWeights)
-        self.big_tiles = {}             # the same kind of table for launches of more than two clips (default: library choice)
-        # Round 3 (lean K loop, 8-wave variants of the small tiles): the narrow text / frames GEMMs on 128x128 tiles with EIGHT waves
-        # (tile 12: two waves per SIMD cover each other's DMA issue and LDS reads; 96 KB, so a 64-row audio workgroup still fits
-        # beside it) and the audio stream's narrow GEMMs on 128x64 tiles with eight waves (tile 14): 5690 -> 5817 mel-frames/s on one
-        # box (profiles/r03_tile_sweep.txt); 64x128 / 8 waves for the text stream is faster alone and 4.6 % slower in the sampler
-        # (144 KB of LDS: nothing else fits on the CU).
-        self.side_tiles = {("t", "cross"): 12, ("t", "out"): 12, ("t", "ff2"): 12, ("t", "ff1"): 6, ("a", "ff1"): 6, ("a", "qkv"): 1,
-                           ("f", "ff1"): 6, ("f", "qkv"): 6, ("f", "cross"): 12, ("f", "out"): 12, ("f", "ff2"): 12}
-        self.main_tile = 14             # tile configuration of the audio stream's narrow-output GEMMs at one clip (-1 = library choice)
-        # bf16x3 mode: (stream, op) -> split-operand tile shape 1..5 of v2a_gemm (default: by shape).  Round 4: the audio / text QKV projections
-        # (N = 3088: 91 tiles of 256x256) on the 8-phase kernel's three-segment form instead of the 2-deep 128x128 split ring (90 us): +1 %
-        self.split_tiles = {("a", "qkv"): 5, ("t", "qkv"): 5}
+        # per-(stream, op) tile choices: the measured rows of TUNED_TILES (module level: each entry with the A/B log that justifies it);
+        # these dicts are the engine's working copies, which bench.py overrides for A/B runs.  An op without an entry takes the stream's
+        # policy tile: `side_tile` on the text / frames streams (set above), `main_tile` on the audio stream's narrow GEMMs (-1 = library).
+        widths = (cfg.dim, cfg.dim_text, cfg.dim_frames, cfg.ff_mult)
+        one_clip = tuned_tiles("bf16", 0, widths)
+        self.side_tiles = {k: v for k, v in one_clip.items() if not (k[0] == "a" and v == 14)}
+        self.main_tile = 14 if any(k[0] == "a" and v == 14 for k, v in one_clip.items()) else -1
+        self.big_tiles = tuned_tiles("bf16", 2, widths)
+        self.split_tiles = tuned_tiles("bf16x3", 0, widths)      # bf16x3 mode: split-operand tile shape 1..5 of v2a_gemm per (stream, op)
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
         # bf16 and bf16x3 modes, up to three clips (bf16 stand-alone: 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
         # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
         self.fuse_xattn = True
-        # Round 4: ONE chain of grouped launches instead of three streams (bf16 mode while a launch cannot fill the chip, i.e. up to two
-        # clips): the audio block of layer i and the text / frames blocks of layer i+1 are independent and run the same op sequence
-        # (x3:1081-1137), so each op of the three is ONE launch (v2a_gemm_grouped / v2a_attention_grouped / v2a_dwconv_grouped) whose
-        # workgroups fill the chip together -- no cross-stream hand-offs, no kernels queueing behind another stream's fat workgroups
-        # (the three-stream schedule ran every kernel ~1.5x its stand-alone time: profiles/r03_timeline_multistream.txt).
+        # Round 4: chains of GROUPED launches (forward_grouped; bf16 and bf16x3 modes while every RMSNorm is folded, i.e. up to two clips).
+        # The audio block of layer i and the text / frames blocks of layer i+1 are independent and run the same op sequence (x3:1081-1137),
+        # so one op of several streams can be ONE launch (v2a_gemm_grouped / v2a_attention_grouped / v2a_dwconv_grouped).  `chains` cuts the
+        # three streams into chains, each on its own HIP stream: one chain (9 launches per layer, no hand-offs), audio | text + frames,
+        # audio + frames | text, or three chains of single launches (= the schedule of forward()).
+        # Measured (profiles/r04_chains_ab.txt, one clip, mel-frames/s): one chain 5282, a | t+f 5400, a+f | t 5630-5730, three chains 5790-5890
+        # = forward()'s three streams 5720-5870; 8 clips per GPU: one chain 8371 against 8833.  A grouped launch takes 0.75x the sum of its
+        # members' single launches (profiles/r04_group_probe.txt), but lock-step launches lose what three independent queues give for free:
+        # every kernel's tail round is filled by the other queues' workgroups, and latency-bound kernels (attention, convolutions) run beside
+        # bandwidth-bound ones.  Default: three chains of single launches.
         self.grouped = True
         self.fold_all_regimes = False       # experiment: RMSNorms folded into GEMM epilogues (and thus grouped chains) at every batch size
-        # how the three streams are cut into chains of grouped launches (forward_grouped): one chain, audio | text + frames,
-        # audio + frames | text, or three chains of single launches
-        # Measured (profiles/r04_chains_ab.txt, one clip, mel-frames/s): one chain 5282, a | t+f 5400, a+f | t 5630-5730, three chains 5790-5890
-        # = forward()'s three streams 5720-5870; 8 clips per GPU: one chain 8371 against 8833.  Lock-step grouped launches lose what three
-        # independent queues give for free: every kernel's tail round is filled by the other queues' workgroups, and latency-bound kernels
-        # (attention, convolutions) run beside bandwidth-bound ones.  Default: three chains (the schedule of forward(), on this scheduler).
         self.chains = (("a",), ("t",), ("f",))
         # tile_hint of each grouped launch (cfg + 1 of v2a_gemm's tile configurations; 7 = the 256x256 8-phase kernel, 13 = 128x128 with
-        # eight waves): measured per group with `bench.py --group-tiles` (profiles/r04_group_tiles.txt)
-        # keys: op for every chain, or ("a+f", op) for the launches of one chain; stand-alone times of every group and tile shape:
+        # eight waves); keys: op for every chain, or ("a+f", op) for the launches of one chain; stand-alone times of every group and tile shape:
         # scripts/group_probe.py, profiles/r04_group_probe.txt (64x128 / 8 waves = 16 is the best narrow tile for two-problem groups)
         self.group_tiles = {"cross": 13, "qkv": 16, "out": 16, "ff1": 7, "ff2": 13,
                             ("a+f", "cross"): 15, ("a+f", "qkv"): 16, ("a+f", "out"): 16, ("a+f", "ff1"): 16, ("a+f", "ff2"): 15,
@@ -483,7 +513,7 @@ class DiTEngine:
 
     def _tuned_dims(self):
         c = self.cfg
-        return (c.dim, c.dim_text, c.dim_frames, c.ff_mult) == (1024, 1280, 512, 4)
+        return ("bf16", 0, (c.dim, c.dim_text, c.dim_frames, c.ff_mult)) in TUNED_TILES
 
     def _fold_gemm(self):
         """... into a GEMM epilogue only up to two clips: the extra bf16 row pieces cost an out-projection launch 2 us of 24 at
@@ -986,9 +1016,10 @@ class DiTEngine:
         main_chain = next(ch for ch in chains if "a" in ch)
         side_chains = [ch for ch in chains if "a" not in ch]
         main = torch.cuda.current_stream()
-        side_streams = [p.get("st"), p.get("sf")]
-        if side_chains and side_streams[0] is None:
-            side_streams = list(process_streams(self.dev)[:2])
+        # without side streams in the plan (multi_stream off, or the bench's stand-alone timing) the side chains run on the main stream,
+        # after the main chain of their layer: every kernel alone on the chip
+        multi = p.get("st") is not None
+        side_streams = [p.get("st"), p.get("sf")] if multi else [main, main]
 
         def hint(chain, op, main_op):
             """tile_hint of one launch: the measured per-group table while it applies (one clip, shipped widths); a launch of one problem
@@ -997,7 +1028,7 @@ class DiTEngine:
                 s_ = chain[0]
                 if s_ == "a":
                     return self._main_hint(main_op).get("tile_hint", 0)
-                return self._side_hint(s_, {"x_tfa": "cross"}.get(main_op, main_op)) if side_chains else 0
+                return self._side_hint(s_, {"x_tfa": "cross"}.get(main_op, main_op))
             if not tuned:
                 return 0
             table = self.group_tiles_split if self.split else self.group_tiles
@@ -1085,16 +1116,24 @@ class DiTEngine:
                 G.append(self._mm_args([(ffh, Fw.inner, Fw.inner)], Fw.w2, xs, M=rows, N=d_, bias=Fw.b2, resid=xs, ldo=d_, ldr=d_, **kw))
             L.gemm_grouped(G, tile_hint=hint(members, "ff2", "ff2"))
 
+        def rec(stream):
+            if not multi:
+                return None
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
+        def wait(stream, e):
+            if multi and e is not None:
+                stream.wait_event(e)
+
         eS = []                               # side chains' blocks of the previous layer done
-        eA = None                             # x of the layer ready (end of the main chain of the previous layer)
-        if side_chains:
-            eA = torch.cuda.Event()
-            eA.record(main)
+        eA = rec(main) if side_chains else None      # x of the layer ready (end of the main chain of the previous layer)
         for i, ly in enumerate(W.layers):
             last = i == c.depth - 1
             nxt = None if last else W.layers[i + 1]
             for e in eS:
-                main.wait_event(e)
+                wait(main, e)
             xn = p["skips"][i] if i < half else xo
             ax, at_, af_ = self._opnd(xc), self._opnd(cur["t"]), self._opnd(cur["f"])
             fused = fz and i >= half
@@ -1116,10 +1155,8 @@ class DiTEngine:
 
             mem = [s_ for s_ in main_chain if s_ == "a" or not last]
             L.gemm_grouped([cross_args(s_) for s_ in mem], tile_hint=hint(mem, "cross", "x_tfa"))
-            eX = None
-            if side_chains and not last:
-                eX = torch.cuda.Event()
-                eX.record(main)             # main has read this layer's text / frames buffers: the side blocks may overwrite them
+            # eX: main has read this layer's text / frames buffers -- the side blocks may overwrite them
+            eX = rec(main) if side_chains and not last else None
             if i < half:
                 src = xn
             else:
@@ -1130,17 +1167,14 @@ class DiTEngine:
             run_chain(main_chain, i, ly, nxt, last, xo, src, ax, None)
             eS = []
             if side_chains and not last:
-                eA_next = torch.cuda.Event()
-                eA_next.record(main)        # x of the next layer is ready
+                eA_next = rec(main)         # x of the next layer is ready
                 for ch, st_ in zip(side_chains, side_streams):
                     with torch.cuda.stream(st_):
-                        st_.wait_event(eA)
+                        wait(st_, eA)
                         L.gemm_grouped([cross_args(s_) for s_ in ch], tile_hint=hint(list(ch), "cross", "cross"))
-                        st_.wait_event(eX)
+                        wait(st_, eX)
                         run_chain(ch, i, ly, nxt, last, None, None, ax, None)
-                        e = torch.cuda.Event()
-                        e.record(st_)
-                        eS.append(e)
+                        eS.append(rec(st_))
                 eA = eA_next
             if not last:
                 cur = {"t": bufs["t"][1], "f": bufs["f"][1]}
