@@ -141,7 +141,10 @@ typedef struct v2a_gemm_args {
    * operands in the L2s of their own XCDs instead of spreading every small GEMM over all eight.  tile_counters: 16 int32 in
    * device memory, zeroed once by the caller and private to ONE stream (launches that may overlap need their own): the last
    * workgroup to claim re-arms them for the next launch.  Which workgroup computes which tile depends on the placement; the
-   * result does not. */
+   * result does not -- PROVIDED the dispatcher deals workgroup i to XCD i % 8 (the default on this part; not under a CU-masked stream
+   * or another partition mode): an XCD of the mask that received fewer workgroups than its chunk has tiles leaves them uncomputed.
+   * The re-arming workgroup adds the number of such tiles to tile_counters[12] (sticky, zeroed only by the caller): non-zero after a
+   * synchronisation = an incomplete launch. */
   int32_t* tile_counters;
   int32_t xcd_mask;
   /* non-zero: the out_bf16 shadow is written in the V2A_BF16_SPLIT layout, row m = [hi_0 .. hi_{N-1} | lo_0 .. lo_{N-1}] of the

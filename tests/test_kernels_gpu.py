@@ -336,7 +336,8 @@ def test_gemm_gate_resid_and_sigmoid(L):
 def test_gemm_xcd_mask_placement(L, mask, tile):
     """v2a_gemm_args.xcd_mask: a launch confined to a subset of the XCDs (workgroups read HW_REG_XCC_ID and claim the tiles of their
     XCD's chunk through tile_counters; 0x1FF = all eight XCDs through the claim path).  Which workgroup computes a tile depends on the
-    dispatch, the result does not: bit-equal to the default placement, and the last workgroup re-arms the counters."""
+    dispatch, the result does not: bit-equal to the default placement, and the last workgroup re-arms the counters -- all sixteen words
+    zero afterwards, word 12 included: it counts tiles an XCD of the mask left unclaimed (an incomplete launch)."""
     M, N, K = 1564, 1024, 1024
     g = _g(mask + tile)
     a = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)

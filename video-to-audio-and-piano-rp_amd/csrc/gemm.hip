@@ -241,8 +241,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const std
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int a = __hip_atomic_fetch_add(p.tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a == (int)gridDim.x - 1) {
+        // every workgroup of the launch has claimed: an XCD of the mask whose claims fell short of its chunk (the dispatcher did not deal
+        // workgroup i to XCD i % 8 -- a CU-masked stream, another partition mode) left tiles uncomputed.  That cannot be repaired from
+        // here; it is COUNTED in tile_counters[12] (sticky) so that the caller can tell an incomplete launch from a complete one.
+        const int nwg = tiles_m * tiles_n;
+        int j = 0, missing = 0;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) p.tile_ctr[2 + x] = 0;
+        for (int x = 0; x < 8; ++x) {
+          if ((p.xcd_mask >> x) & 1) {
+            const int lo = (int)((int64_t)nwg * j / p.xcd_cnt), hi = (int)((int64_t)nwg * (j + 1) / p.xcd_cnt);
+            if (p.tile_ctr[2 + x] < hi - lo) missing += hi - lo - p.tile_ctr[2 + x];
+            ++j;
+          }
+          p.tile_ctr[2 + x] = 0;
+        }
+        if (missing) p.tile_ctr[12] += missing;
         p.tile_ctr[0] = 0;
       }
       *slot = L;
