@@ -62,10 +62,10 @@ _T0 = time.perf_counter()
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PMC_FILES = ("r03_pmc1_summary.csv", "r03_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
-ROCPROF_STATS = "r03_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
-ROCPROF_STATS_MULTI = "r03_kernel_stats_multistream.csv"         # ... of the production configuration (three streams)
-ROCPROF_STATS_8CLIPS = "r03_kernel_stats_8clips.csv"             # ... of `bench.py --clips-per-gpu 8`
+PMC_FILES = ("r04_pmc1_summary.csv", "r04_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
+ROCPROF_STATS = "r04_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
+ROCPROF_STATS_MULTI = "r04_kernel_stats_multistream.csv"         # ... of the production configuration (three streams)
+ROCPROF_STATS_8CLIPS = "r04_kernel_stats_8clips.csv"             # ... of `bench.py --clips-per-gpu 8`
 
 
 def main():

@@ -25,10 +25,11 @@ def test_profile_files_named_by_bench_exist(bench):
 
 
 @pytest.mark.parametrize("key,stats", [("gemm<bf16,a_bf16,resid,f32,tile12>", "ROCPROF_STATS_MULTI"), ("gemm<bf16,a_bf16,resid,f32>", "ROCPROF_STATS"),
-                                       ("gemm<bf16,a_bf16,gate_resid,f32,tile14>", "ROCPROF_STATS_MULTI")])
+                                       ("gemm<bf16,a_bf16,gate_resid,f32,tile14>", "ROCPROF_STATS_MULTI"), ("gemm<bf16,a_bf16,geglu,bf16,tile6>", "ROCPROF_STATS_MULTI"),
+                                       ("gemm<bf16,a_bf16,geglu,bf16>", "ROCPROF_STATS_8CLIPS")])
 def test_rocprof_block_finds_the_dominant_kernel_classes(bench, key, stats):
     r = bench.rocprof_avg(key, 6.7e9, 2.5e15 / 1e12, getattr(bench, stats))
-    assert r is not None and r["calls"] > 100 and 5.0 < r["avg_us"] < 200.0 and "gemm_bf16_dma_kernel" in r["source"], r
+    assert r is not None and r["calls"] > 100 and 5.0 < r["avg_us"] < 500.0 and ("gemm_bf16_dma_kernel" in r["source"] or "gemm_bf16_8ph_kernel" in r["source"]), r
 
 
 def test_traffic_block_reports_algorithmic_bytes_and_ratio(bench):
