@@ -66,6 +66,7 @@ PMC_FILES = ("r04_pmc1_summary.csv", "r04_pmc2_summary.csv")    # FETCH_SIZE pas
 ROCPROF_STATS = "r04_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
 ROCPROF_STATS_MULTI = "r04_kernel_stats_multistream.csv"         # ... of the production configuration (three streams)
 ROCPROF_STATS_8CLIPS = "r04_kernel_stats_8clips.csv"             # ... of `bench.py --clips-per-gpu 8`
+ROCPROF_STATS_8CLIPS_ALONE = "r04_kernel_stats_8clips_singlestream.csv"   # ... of `bench.py --clips-per-gpu 8 --single-stream`: every kernel alone on the chip
 
 
 def main():
@@ -652,7 +653,8 @@ def roofline_leg(model, L, args, production=False):
                       "MB_per_launch": round(a["bytes"] / a["launches"] / 1e6, 3), "achieved_GBs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
             # the same kernel in the committed rocprofv3 summary of this shape: kernel-only duration, without the ~2 us of event packets
             # the live figure includes (they are a quarter of a 10 us memory-bound launch)
-            rp = rocprof_hbm(k, a["bytes"] / a["launches"], ROCPROF_STATS_8CLIPS if model.engine().plan["B"] >= 8 else ROCPROF_STATS_MULTI)
+            # (the live figure times each kernel alone on one stream: the matching summaries are the single-stream ones)
+            rp = rocprof_hbm(k, a["bytes"] / a["launches"], ROCPROF_STATS_8CLIPS_ALONE if model.engine().plan["B"] >= 8 else ROCPROF_STATS)
             if rp:
                 hbm[k]["rocprof"] = rp
 

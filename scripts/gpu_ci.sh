@@ -155,6 +155,8 @@ for s in "$@"; do
           mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
     prof8) rm -rf /tmp/prof8; run prof8 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -- python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
           mkdir -p gpurun_out/prof; cp /tmp/prof8/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_8clips.csv ;;
+    prof8s) rm -rf /tmp/prof8s; run prof8s 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8s -- python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --single-stream --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+          mkdir -p gpurun_out/prof; cp /tmp/prof8s/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_8clips_singlestream.csv ;;
     prof1_old) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched --no-video2roll --no-vocoder
           mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
     prof_v2r) rm -rf /tmp/profv; run prof_v2r 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profv -- python bench.py --steps 1 --warmup 0 --cfm-steps 4 --no-cpu-baseline --no-roofline --no-batched

@@ -20,7 +20,7 @@ def bench():
 
 
 def test_profile_files_named_by_bench_exist(bench):
-    for fn in (*bench.PMC_FILES, bench.ROCPROF_STATS, bench.ROCPROF_STATS_MULTI, bench.ROCPROF_STATS_8CLIPS):
+    for fn in (*bench.PMC_FILES, bench.ROCPROF_STATS, bench.ROCPROF_STATS_MULTI, bench.ROCPROF_STATS_8CLIPS, bench.ROCPROF_STATS_8CLIPS_ALONE):
         assert os.path.isfile(os.path.join(ROOT, "profiles", fn)), fn
 
 
@@ -70,5 +70,5 @@ def test_summary_fields_pick_the_parity_qualified_mode(bench):
 
 def test_rocprof_hbm_block_finds_the_memory_bound_kernels(bench):
     for key, mb in (("rmsnorm<bf16>", 100.0), ("dwconv+norm", 120.0), ("cfg_euler", 12.3)):
-        r = bench.rocprof_hbm(key, mb * 1e6, bench.ROCPROF_STATS_8CLIPS)
+        r = bench.rocprof_hbm(key, mb * 1e6, bench.ROCPROF_STATS_8CLIPS_ALONE)
         assert r is not None and r["calls"] > 10 and 1.0 < r["avg_us"] < 200.0, (key, r)
