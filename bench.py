@@ -399,6 +399,16 @@ def summary_fields(res):
                     if best is None or row["share"] > best[1]:
                         fr[key] = (round(row["tflops"] / PEAK_BF16_TFLOPS, 4), row["share"])
             summ["batched_8clips"].update({"all_gemm_frac": r8["all_gemm_frac"], **{"frac_" + k: v[0] for k, v in fr.items()}})
+            # the same classes from the committed kernel-only summary of `--clips-per-gpu 8 --single-stream` (no event packets)
+            for k, row in r8["kernels"].items():
+                if k.startswith("gemm<bf16") and "tflops" in row:
+                    rp = rocprof_avg(k, row["tflops"] * 1e12 * row["avg_us"] * 1e-6, PEAK_BF16_TFLOPS, ROCPROF_STATS_8CLIPS_ALONE)
+                    if rp:
+                        row["rocprof"] = {"avg_us": rp["avg_us"], "frac": rp["frac"]}
+                        cls = k.split(",")[2]
+                        key = "qkv_store_bf16" if (cls == "store" and k.split(",")[3].startswith("bf16")) else cls
+                        if fr.get(key, (None, -1))[1] == row["share"]:
+                            summ["batched_8clips"]["frac_%s_rocprof" % key] = rp["frac"]
             if "roofline" in res:
                 res["roofline"].update({"clips8_all_gemm_frac": r8["all_gemm_frac"], "clips8_mel_frames_per_s": b["mel_frames_per_s"],
                                         **{"clips8_frac_" + k: v[0] for k, v in fr.items()}})
