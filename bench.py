@@ -401,7 +401,7 @@ def summary_fields(res):
             summ["batched_8clips"].update({"all_gemm_frac": r8["all_gemm_frac"], **{"frac_" + k: v[0] for k, v in fr.items()}})
             # the same classes from the committed kernel-only summary of `--clips-per-gpu 8 --single-stream` (no event packets)
             for k, row in r8["kernels"].items():
-                if k.startswith("gemm<bf16") and "tflops" in row:
+                if k.startswith("gemm<bf16") and "tflops" in row and "avg_us" in row:
                     rp = rocprof_avg(k, row["tflops"] * 1e12 * row["avg_us"] * 1e-6, PEAK_BF16_TFLOPS, ROCPROF_STATS_8CLIPS_ALONE)
                     if rp:
                         row["rocprof"] = {"avg_us": rp["avg_us"], "frac": rp["frac"]}
