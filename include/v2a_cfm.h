@@ -157,11 +157,16 @@ typedef struct v2a_gemm_args {
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
 /* Grouped form (ABI 7): nprob (1..3) independent problems behind ONE kernel launch -- the same Linear of the audio, text and frames
  * blocks of a layer (x3:1081-1137: A_i, T_i+1 and F_i+1 do not depend on each other), whose workgroups then share the chip inside one
- * launch instead of three kernels queueing on three streams.  All problems bf16 x bf16 with dense rows and 16-byte aligned epilogue
- * operands; one tile_hint for the group (0 = by shape); the epilogues of a group are either all STORE to bf16 (QKV projections, RoPE
- * allowed), all GEGLU to bf16, or fp32 results with any mix of STORE / RESID / GATE_RESID (one kernel: an absent residual reads as 0,
- * an absent gate as 1 -- bit-identical to the separate epilogues).  Problems are dispatched longest K first.  The result of every
- * problem equals its own v2a_gemm call bit for bit (same K order per output element, same epilogue expressions). */
+ * launch instead of three kernels queueing on three streams.  All problems bf16 x bf16 -- all with plain or all with split (V2A_BF16_SPLIT)
+ * operands -- with dense rows and 16-byte aligned epilogue operands; one tile_hint for the group (0 = by shape; plain operands: k + 1 =
+ * tile configuration k of v2a_tuning.gemm_force_tile, supported 0, 1, 3, 6, 12, 14, 15; split operands: 1..5 as for v2a_gemm); the
+ * epilogues of a group are either all STORE (to bf16; split operands: to fp32; RoPE allowed), all GEGLU (to bf16; split operands: to
+ * hi | lo planes), or fp32 results with any mix of STORE / RESID / GATE_RESID (one kernel: an absent residual reads as 0, an absent gate as
+ * 1 -- bit-identical to the separate epilogues).  Problems are dispatched longest K first.  The result of every problem equals its own
+ * v2a_gemm call on the same tile form bit for bit (same K order per output element, same epilogue expressions).  Measured
+ * (profiles/r04_group_probe.txt): a group takes 0.75x the sum of its members' single launches alone on the chip; inside the sampler the
+ * three-queue schedule of single launches is faster than any chain of grouped launches, which is why the sampler's
+ * default does not group. */
 int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_stream_t stream);
 /* sizeof(v2a_gemm_args) as the library was built: a binding checks its mirror of the struct against this */
 int v2a_gemm_args_size(void);
