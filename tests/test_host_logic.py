@@ -127,3 +127,22 @@ def test_collate_and_shards():
         s, e, per = v2a_amd.shard_range(13, r, 8)
         covered += list(range(s, e))
     assert covered == list(range(13))
+
+
+def test_tuned_tiles_table_names_existing_ab_logs():
+    """dit.TUNED_TILES: one table of measured tile choices keyed by (mode, regime, widths); every entry names the A/B record that
+    justifies it, and a record that is a file must exist under profiles/."""
+    import os
+    import re
+    from v2a_amd.dit import TUNED_TILES, SHIPPED_WIDTHS, tuned_tiles
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert ("bf16", 0, SHIPPED_WIDTHS) in TUNED_TILES and ("bf16x3", 0, SHIPPED_WIDTHS) in TUNED_TILES
+    for (mode, regime, widths), rows in TUNED_TILES.items():
+        assert mode in ("bf16", "bf16x3") and regime in (0, 1, 2) and len(widths) == 4
+        for (stream, op), (tile, log) in rows.items():
+            assert stream in "atf" and op in ("x_tfa", "skip", "qkv", "out", "q2", "out2", "ff1", "ff2", "cross")
+            assert 0 <= tile <= 15 and isinstance(log, str) and log
+            for fn in re.findall(r"profiles/[\w.]+\.txt", log):
+                assert os.path.isfile(os.path.join(root, fn)), fn
+    assert tuned_tiles("bf16", 0, (64, 64, 64, 4)) == {}            # unmeasured widths: policy tiles only
+    assert tuned_tiles("bf16", 0, SHIPPED_WIDTHS)[("t", "ff1")] == 6

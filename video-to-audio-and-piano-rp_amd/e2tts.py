@@ -435,7 +435,9 @@ class E2TTS:
                 raise NotImplementedError("lens != duration (audio-prompted infilling) needs cond_proj_in (E2TTS(if_cond_proj_in=True), "
                                           "x3:1365): with the shipped configuration the reference fails at x3:2034 as well")
             if self.audiocond_snr is not None:
-                raise NotImplementedError("audiocond_snr: the reference adds fresh device noise to the prompt at every step (x3:2115-2125)")
+                # (the reference cannot get through this branch either: add_noise indexes signal[mask] with the (b, n, 1) cond_mask of
+                # x3:2213 on the (b, n, C) prompt, which torch refuses -- IndexError at x3:2124 -- so there is no behaviour to mirror)
+                raise NotImplementedError("audiocond_snr: the reference adds fresh device noise to the prompt at every step (x3:2115-2125, 2228)")
             condp = torch.nn.functional.pad(cond.detach().to("cpu", torch.float32)[:, :n], (0, 0, 0, max(0, n - cond_seq_len)))   # x3:2212
             cond_mask = lens_to_mask(lens, n)[..., None]                                                            # x3:2196, 2213-2214
             step_cond = torch.where(cond_mask, condp, torch.zeros_like(condp))                                      # x3:2228
