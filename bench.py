@@ -93,7 +93,6 @@ def main():
     ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered, 2 lock-step)")
     ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
     ap.add_argument("--gemm-force-tile", type=int, default=-1, help="v2a_set_tuning: one tile configuration for every bf16 GEMM (experiment)")
-    ap.add_argument("--ring-pipe", action="store_true", help="A/B: ring GEMM kernel with the software-pipelined K loop")
     ap.add_argument("--persistent", action="store_true", help="A/B: 8-phase GEMM kernel with persistent workgroups and cross-tile prefetch")
     ap.add_argument("--xcd-1x8", action="store_true", help="A/B: round-1 XCD tile order (column strips) instead of the per-shape rectangle grid")
     ap.add_argument("--interleave-capture", type=int, default=-1, help="A/B: 1 = interleave the capture order of audio and side blocks")
@@ -143,10 +142,10 @@ def main():
     from v2a_amd import _lib as L
     from v2a_amd.synth import random_state_dict, synthetic_conditioning
 
-    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8 or args.gemm_8phase_min_tiles > 0 or args.attn_one_group_from > 0 or args.persistent or args.ring_pipe:
+    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8 or args.gemm_8phase_min_tiles > 0 or args.attn_one_group_from > 0 or args.persistent:
         L.set_tuning(force_tile=args.gemm_force_tile, eight_phase=(args.gemm_8phase if args.gemm_8phase >= 0 else None),
                      eight_phase_min_tiles=args.gemm_8phase_min_tiles, xcd_order_1x8=args.xcd_1x8,
-                     attn_one_group_from=args.attn_one_group_from, persistent_8phase=args.persistent, ring_pipe=args.ring_pipe)
+                     attn_one_group_from=args.attn_one_group_from, persistent_8phase=args.persistent)
     cfg = v2a_amd.DiTConfig()
     if args.clips_per_gpu <= 0:
         args.clips_per_gpu = 1 if world == 1 else 8

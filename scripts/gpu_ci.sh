@@ -60,11 +60,6 @@ for s in "$@"; do
            TAILN=0 run pa_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v ${PA_EXTRA:-}
            echo "--- [$v] ${PA_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/pa_x.log | head -1) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/pa_x.log | head -1)"
          done ;;
-    pipeprobe) TAILN=12 run pipeprobe 600 python scripts/probes/ring_pipe_probe.py ;;
-    pipeab) for v in "" "--ring-pipe" "" "--ring-pipe"; do
-           TAILN=0 run pp_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $v ${PP_EXTRA:-}
-           echo "--- [$v] ${PP_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/pp_x.log | head -1)"
-         done ;;
     soak) TAILN=12 run soak 1100 python scripts/probes/soak_probe.py ;;
     gprobe) TAILN=60 run gprobe 600 python scripts/group_probe.py ${GP_ARGS:-} ;;
     schedtests) TAILN=15 run schedtests 900 python -m pytest tests/test_grouped_gpu.py tests/test_sampler_gpu.py tests/test_full_shape_gpu.py -q -m gpu --tb=short -k "grouped" ;;

@@ -171,16 +171,15 @@ def lib():
 
 
 def set_tuning(force_tile: int = -1, k_rotation: bool = False, eight_phase: int | None = None, eight_phase_min_tiles: int = 0,
-               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0, persistent_8phase: bool = False, ring_pipe: bool = False):
+               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0, persistent_8phase: bool = False):
     """Tile-selection overrides (A/B measurements); `set_tuning()` restores the library defaults.
-    persistent_8phase=True: the 8-phase GEMM kernel with persistent workgroups and cross-tile prefetch (off by default, v2a_tuning.reserved);
-    ring_pipe=True: the ring GEMM kernel with the software-pipelined K loop (fragment reads of tile k+1 under the MFMAs of tile k)."""
+    persistent_8phase=True: the 8-phase GEMM kernel with persistent workgroups and cross-tile prefetch (off by default, v2a_tuning.reserved)."""
     if (force_tile == -1 and not k_rotation and eight_phase is None and eight_phase_min_tiles == 0 and dwconv_rows_per_wave == 0
-            and not xcd_order_1x8 and attn_one_group_from == 0 and not persistent_8phase and not ring_pipe):
+            and not xcd_order_1x8 and attn_one_group_from == 0 and not persistent_8phase):
         check(lib().v2a_set_tuning(None))
         return
     t = Tuning(force_tile, 1 if k_rotation else 0, 1 if eight_phase is None else eight_phase, eight_phase_min_tiles, dwconv_rows_per_wave,
-               1 if xcd_order_1x8 else 0, attn_one_group_from, (C.c_int32 * 1)((64 if persistent_8phase else 0) | (128 if ring_pipe else 0)))
+               1 if xcd_order_1x8 else 0, attn_one_group_from, (C.c_int32 * 1)(64 if persistent_8phase else 0))
     check(lib().v2a_set_tuning(C.byref(t)))
 
 

@@ -192,10 +192,10 @@ __device__ __forceinline__ void ring_wait(int younger) {
 // ([A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]) moved 3x the bytes and needed one launch per logical K segment.
 // GROUPED: the argument is a GemmGroup and the workgroup first picks its problem (gemm_common.h); everything after that is the
 // single-problem kernel on that problem's parameter block.
-// PIPE (round 4, A/B: v2a_tuning.reserved bit 7): the fragment reads of K tile kt + 1 are issued BEHIND the barrier of step kt and land
-// while the MFMAs of tile kt run (two fragment register sets, loop unrolled by 6 = lcm(ring positions, register sets)), instead of
-// every step paying barrier -> LDS read latency -> first MFMA in series; all three ring stages are in flight from the prologue on.
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false, bool GROUPED = false, bool PIPE = false>
+// (Round 4 measured a software-pipelined form of the K loop -- the fragment reads of tile k + 1 issued behind the barrier of step k into a
+// second register set, landing under the MFMAs of tile k: 1-5 % SLOWER at equal occupancy, 16-27 % where the extra registers cost a
+// resident workgroup, profiles/r04_ring_pipe_probe.txt.  The exposed part of a K step is not the LDS read latency; the form is not kept.)
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false, bool GROUPED = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const std::conditional_t<GROUPED, v2a_detail::GemmGroup, GemmParams> arg) {
   int bid_ = blockIdx.x;
   const GemmParams* pp_;
@@ -476,66 +476,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const std
     }
   };
   static_assert(NST >= 2 && NST <= 6, "ring depth");
-  if constexpr (PIPE) {
-    static_assert(NST == 3 && !S3, "the pipelined K loop is written for the 3-deep ring of plain bf16 operands");
-    if (NST - 1 < nk) issue(NST - 1);          // the third stage is free too: three tiles in flight from the start
-    bf16x8 fa[2][2][TM], fb[2][2][TN];         // [register set][k half][tile]
-    auto read_frags = [&](auto stage_c, auto set_c) {
-      constexpr int STAGE = decltype(stage_c)::value, SET = decltype(set_c)::value;
-      const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
-      const bf16_t* Ws = As + BM * 64;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * WM + i * 16 + lr;
-          fa[SET][kk][i] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * WN + j * 16 + lr;
-          fb[SET][kk][j] = *reinterpret_cast<const bf16x8*>(Ws + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
-        }
-      }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    // tile 0 has landed for this wave once only the two younger tiles' DMAs remain outstanding; then for every wave
-    ring_wait<NST - 1, LPW>(nk - 1);
-    __builtin_amdgcn_s_barrier();
-    read_frags(I0{}, I0{});
-    // step kt: tile kt multiplies out of register set SET (requested one step ago), tile kt + 1 (ring stage NEXT) is requested into
-    // the other set, tile kt + 3 is requested from memory into the stage tile kt was read from
-    auto step = [&](auto next_c, auto free_c, auto set_c, int kt) {
-      constexpr int NEXT = decltype(next_c)::value, FREE = decltype(free_c)::value, SET = decltype(set_c)::value;
-      // this wave's reads of tile kt's stage are complete BEFORE the barrier that lets other waves' DMAs refill it
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (kt + 1 < nk) ring_wait<NST - 2, LPW>(nk - 2 - kt);      // tile kt + 1 has landed: only tile kt + 2 may still be outstanding
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) read_frags(std::integral_constant<int, NEXT>{}, std::integral_constant<int, SET ^ 1>{});
-      if (kt + NST < nk) issue(FREE);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[SET][kk][i], fb[SET][kk][j], acc[i][j], 0, 0, 0);
-      // pin: [the next tile's fragment reads] [the DMA issue] [this tile's MFMAs]
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, LPW, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
-    };
-    for (int kt = 0; kt < nk; kt += 6) {
-      step(I1{}, I0{}, I0{}, kt);
-      if (kt + 1 < nk) step(I2{}, I1{}, I1{}, kt + 1);
-      if (kt + 2 < nk) step(I0{}, I2{}, I0{}, kt + 2);
-      if (kt + 3 < nk) step(I1{}, I0{}, I1{}, kt + 3);
-      if (kt + 4 < nk) step(I2{}, I1{}, I0{}, kt + 4);
-      if (kt + 5 < nk) step(I0{}, I2{}, I1{}, kt + 5);
-    }
-  } else
   for (int kt = 0; kt < nk; kt += NST) {
     tile(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < nk) tile(std::integral_constant<int, 1>{}, kt + 1);
@@ -554,7 +494,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const std
   }
 }
 
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST, bool S3 = false, bool PIPE = false>
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST, bool S3 = false>
 int launch_dma(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
   v2a_detail::fill_tile_map(p, BM, BN);
@@ -567,7 +507,7 @@ int launch_dma(const GemmParams& p_in, hipStream_t s) {
   if (p.tile_ctr) tiles = 8 * ((tiles + p.xcd_cnt - 1) / p.xcd_cnt);
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
-  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3, false, PIPE>;
+  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3>;
   static std::atomic<uint64_t> lds_set{0};
   if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm(dma)")) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WGM * WGN), smem, s, p);
@@ -592,28 +532,6 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
       break;
   }
   return v2a_fail(V2A_ERR_ARG, "v2a_gemm(dma): unsupported epilogue %d / out_dtype %d", a->epilogue, a->out_dtype);
-}
-
-// the software-pipelined K loop (PIPE) on the 3-deep ring: the tile shapes the one-clip sampler uses
-template <int BM, int BN, int WGM, int WGN>
-int dispatch_dma_pipe(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
-  const bool out_f32 = a->out_dtype == V2A_F32;
-  switch (a->epilogue) {
-    case V2A_EPI_STORE:
-      return out_f32 ? launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN, 3, false, true>(p, s) : launch_dma<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN, 3, false, true>(p, s);
-    case V2A_EPI_GEGLU:
-      if constexpr ((BN / WGN / 16) % 2 == 0) {
-        if (!out_f32) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, 3, false, true>(p, s);
-      }
-      break;
-    case V2A_EPI_RESID:
-      if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN, 3, false, true>(p, s);
-      break;
-    case V2A_EPI_GATE_RESID:
-      if (out_f32) return launch_dma<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, 3, false, true>(p, s);
-      break;
-  }
-  return v2a_fail(V2A_ERR_ARG, "v2a_gemm(dma, pipelined): unsupported epilogue %d / out_dtype %d", a->epilogue, a->out_dtype);
 }
 
 // split-bf16 operands (bf16x3 mode): the epilogues that mode uses
@@ -712,7 +630,6 @@ v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 int v2a_detail::g_attn_one_group_from = 1536;
 int v2a_detail::g_probe_dbg = 0;       // v2a_tuning.reserved[0]: read by probe builds only
-int v2a_detail::g_ring_pipe = 0;        // v2a_tuning.reserved[0] bit 7: ring kernel with the software-pipelined K loop (A/B)
 int v2a_detail::g_8ph_persistent = 0;   // v2a_tuning.reserved[0] bit 6 switches it on (A/B: +2.5 % per launch alone, -2.3 % in the 8-clip sampler)
 int v2a_detail::g_dwconv_stream = 1;   // streaming depthwise conv for chip-filling launches (dwconv_rows_per_wave = -1 switches it off: A/B)
 
@@ -726,7 +643,6 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
     v2a_detail::g_attn_one_group_from = 1536;
     v2a_detail::g_probe_dbg = 0;
     v2a_detail::g_8ph_persistent = 0;
-    v2a_detail::g_ring_pipe = 0;
     return V2A_OK;
   }
   // every field is checked before any is assigned: a rejected call leaves the previous tuning whole
@@ -743,7 +659,6 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
                                t->gemm_xcd_order_1x8 ? 0 : 1, t->reserved[0]};
   v2a_detail::g_probe_dbg = t->reserved[0];
   v2a_detail::g_8ph_persistent = (t->reserved[0] & 64) ? 1 : 0;
-  v2a_detail::g_ring_pipe = (t->reserved[0] & 128) ? 1 : 0;
   return V2A_OK;
 }
 
@@ -957,16 +872,6 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
       V2A_REQUIRE(dense, "v2a_gemm: tile_hint 7 (256x256 8-phase) needs dense rows and 16-byte aligned epilogue operands");
       return v2a_detail::launch_gemm_8phase(p, a->epilogue, a->out_dtype, s);
     }
-    if (v2a_detail::g_ring_pipe && !a->a_row_offset && !a->a_ktile_offset) {
-      switch (a->tile_hint - 1) {
-        case 1: return dispatch_dma_pipe<128, 128, 2, 2>(a, p, s);
-        case 12: return dispatch_dma_pipe<128, 128, 2, 4>(a, p, s);
-        case 14: return dispatch_dma_pipe<128, 64, 4, 2>(a, p, s);
-        case 15: return dispatch_dma_pipe<64, 128, 2, 4>(a, p, s);
-        case 3: case 4: return dispatch_dma_pipe<64, 64, 2, 2>(a, p, s);
-        default: break;
-      }
-    }
     switch (a->tile_hint - 1) {
       case 5: return dispatch_dma<256, 256, 2, 4, 2>(a, p, s);
       case 0: return dispatch_dma<128, 256, 2, 4>(a, p, s);
@@ -1024,9 +929,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     case 2: return dispatch_dma<128, 64, 2, 2>(a, p, s);    // 4 waves,  72 KB, 2 workgroups/CU
     case 7: return dispatch_dma<64, 128, 2, 2, 6>(a, p, s); // 4 waves, 144 KB: 6-deep ring, 1 workgroup/CU (<= 256 tiles)
     case 8: return dispatch_dma<64, 64, 2, 2, 6>(a, p, s);  // 4 waves,  96 KB: 6-deep ring, 1 workgroup/CU (<= 256 tiles)
-    default:
-      if (v2a_detail::g_ring_pipe && !a->a_row_offset && !a->a_ktile_offset) return dispatch_dma_pipe<64, 64, 2, 2>(a, p, s);
-      return dispatch_dma<64, 64, 2, 2>(a, p, s);    // 4 waves,  48 KB, 3 workgroups/CU
+    default: return dispatch_dma<64, 64, 2, 2>(a, p, s);    // 4 waves,  48 KB, 3 workgroups/CU
   }
 }
 

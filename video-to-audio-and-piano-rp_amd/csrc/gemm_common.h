@@ -96,7 +96,6 @@ extern int g_attn_one_group_from;    // v2a_attention: workgroup count from whic
 extern int g_dwconv_rows_per_wave;   // 4 or 8 (v2a_set_tuning)
 extern int g_probe_dbg;              // v2a_tuning.reserved[0] (probe builds)
 extern int g_dwconv_stream;          // 0: never use the streaming depthwise conv (v2a_tuning.dwconv_rows_per_wave = -1)
-extern int g_ring_pipe;              // ring kernel: software-pipelined K loop (v2a_tuning.reserved bit 7, A/B)
 extern int g_8ph_persistent;         // 8-phase kernel: persistent workgroups with cross-tile prefetch (0: one workgroup per tile, A/B)
 
 // 256x256 8-phase kernel (gemm_8phase.hip)
