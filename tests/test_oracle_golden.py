@@ -165,3 +165,53 @@ def test_oracle_audio_prompt_fixture_and_properties():
     same = O.sample(P, cfg, t("y0"), t("text"), t("roll"), t("ctx"), t("ctx_mask"), duration=t("duration"), cond=t("cond"), lens=t("duration"), **kw)
     none = O.sample(P, cfg, t("y0"), t("text"), t("roll"), t("ctx"), t("ctx_mask"), duration=t("duration"), **kw)
     assert torch.equal(same, none)
+
+
+# ---- the oracle's generic arithmetic against torch's own independent implementations ---------------------------------------------
+# (This does NOT pin the x-transformers-specific choices A1-A13 -- those stay unpinned, SURVEY 8c -- it rules out restatement slips in the
+# parts any implementation must agree on: the attention core, the depthwise convolution, the GEGLU feed-forward, the RMS normalisation.)
+
+def test_attention_core_matches_torch_sdpa(small):
+    """softclamp off, head gates saturated open (weight 0, bias +40: sigmoid == 1 in fp32), no rotary: what is left is
+    softmax(q k^T / sqrt(d) | key mask) v followed by to_out -- torch.nn.functional.scaled_dot_product_attention on the same projections."""
+    import torch.nn.functional as F
+    P, cfg = dict(small["P"]), small["cfg"]
+    pre = "transformer.layers.1.0.3"
+    P[f"{pre}.to_v_head_gate.weight"] = torch.zeros_like(P[f"{pre}.to_v_head_gate.weight"])
+    P[f"{pre}.to_v_head_gate.bias"] = torch.full_like(P[f"{pre}.to_v_head_gate.bias"], 40.0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 44, cfg.dim, generator=g)
+    mask = O.lens_to_mask(torch.tensor([44, 30]), 44)
+    with torch.no_grad():
+        got = O.attention(P, pre, x, cfg.heads, 64, None, mask, O.OracleOptions(softclamp=0.0, zero_masked_queries=False))
+        split = lambda t: t.reshape(2, 44, cfg.heads, 64).permute(0, 2, 1, 3)
+        q, k, v = (split(F.linear(x, P[f"{pre}.to_{n}.weight"])) for n in "qkv")
+        ref = F.scaled_dot_product_attention(q, k, v, attn_mask=mask[:, None, None, :])
+        ref = F.linear(ref.permute(0, 2, 1, 3).reshape(2, 44, -1), P[f"{pre}.to_out.weight"])
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5)
+
+
+def test_depthwise_conv_matches_torch_conv1d(small):
+    """DepthwiseConv (x3:495-528) on an unmasked batch: Conv1d(groups = dim, padding = k // 2) followed by SiLU."""
+    import torch.nn.functional as F
+    P = small["P"]
+    w, b = P["transformer.layers.0.0.1.dw_conv1d.0.weight"], P["transformer.layers.0.0.1.dw_conv1d.0.bias"]
+    x = torch.randn(2, 44, w.shape[0], generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        got = O.depthwise_conv(x, w, b, None)
+        ref = F.silu(F.conv1d(x.transpose(1, 2), w, b, padding=w.shape[-1] // 2, groups=w.shape[0])).transpose(1, 2)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_feedforward_and_rmsnorm_match_torch_modules(small):
+    import torch.nn.functional as F
+    P, cfg = small["P"], small["cfg"]
+    pre = "transformer.layers.0.0.9"
+    x = torch.randn(3, 7, cfg.dim, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        a, gt = F.linear(x, P[f"{pre}.ff.0.proj.weight"], P[f"{pre}.ff.0.proj.bias"]).chunk(2, dim=-1)
+        ref = F.linear(a * F.gelu(gt), P[f"{pre}.ff.2.weight"], P[f"{pre}.ff.2.bias"])
+        np.testing.assert_allclose(O.feedforward(P, pre, x).numpy(), ref.numpy(), atol=1e-5)
+        g = 1 + 0.1 * torch.randn(cfg.dim, generator=torch.Generator().manual_seed(6))
+        # x / rms(x) * g: torch's rms_norm with eps -> 0 (x-transformers' F.normalize form clamps the NORM at 1e-12 instead)
+        np.testing.assert_allclose(O.rmsnorm(x, g).numpy(), F.rms_norm(x, (cfg.dim,), g, eps=1e-30).numpy(), atol=1e-5)
