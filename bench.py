@@ -407,7 +407,9 @@ def summary_fields(res):
                         row["rocprof"] = {"avg_us": rp["avg_us"], "frac": rp["frac"]}
                         cls = k.split(",")[2]
                         key = "qkv_store_bf16" if (cls == "store" and k.split(",")[3].startswith("bf16")) else cls
-                        if fr.get(key, (None, -1))[1] == row["share"]:
+                        # (only the classes that run on ONE kernel instantiation at this shape -- the 8-phase kernel -- have a
+                        # kernel row with the same launch mix; the residual classes mix it with the 128x256 ring)
+                        if fr.get(key, (None, -1))[1] == row["share"] and key in ("geglu", "qkv_store_bf16"):
                             summ["batched_8clips"]["frac_%s_rocprof" % key] = rp["frac"]
             if "roofline" in res:
                 res["roofline"].update({"clips8_all_gemm_frac": r8["all_gemm_frac"], "clips8_mel_frames_per_s": b["mel_frames_per_s"],
