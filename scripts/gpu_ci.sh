@@ -51,7 +51,7 @@ for s in "$@"; do
            TAILN=0 run ch_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${CH_EXTRA:-}
            echo "--- chains [$v] ${CH_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/ch_x.log | head -1)"
          done ;;
-    x3qkv) for v in "_" "a.qkv=5,t.qkv=5" "a.qkv=5,t.qkv=5,f.qkv=5" "_"; do
+    x3qkv) for v in ${X3_SWEEP:-"_" "a.qkv=5,t.qkv=5" "a.qkv=5,t.qkv=5,f.qkv=5" "_"}; do
            a=""; [ "$v" != "_" ] && a="--side-tiles $v"
            TAILN=0 run x3_x 300 python bench.py --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a
            echo "--- bf16x3 split tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/x3_x.log | head -1)"
