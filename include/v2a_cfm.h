@@ -51,7 +51,7 @@ enum {
   V2A_ERR_LAUNCH = -2  /* hipGetLastError() after launch */
 };
 
-int v2a_abi_version(void);        /* 7 */
+int v2a_abi_version(void);        /* 8 */
 const char* v2a_last_error(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -134,19 +134,6 @@ typedef struct v2a_gemm_args {
   const float* row_ssq;
   int64_t ld_row_ssq;
   int32_t row_ssq_parts, row_norm_dim;
-  /* XCD-subset placement (bf16 x bf16 LDS-DMA ring kernels; ignored by the others).  xcd_mask: bit x set = the launch may use
-   * XCD x (0 or 0xFF = all eight, the default placement).  With a proper subset the grid is 8 * ceil(tiles / XCDs in the mask)
-   * workgroups; one that finds itself on an XCD of the mask (HW_REG_XCC_ID) claims the next tile of that XCD's contiguous chunk
-   * of the tile order through tile_counters, the others return at once -- so three concurrent streams can each keep their
-   * operands in the L2s of their own XCDs instead of spreading every small GEMM over all eight.  tile_counters: 16 int32 in
-   * device memory, zeroed once by the caller and private to ONE stream (launches that may overlap need their own): the last
-   * workgroup to claim re-arms them for the next launch.  Which workgroup computes which tile depends on the placement; the
-   * result does not -- PROVIDED the dispatcher deals workgroup i to XCD i % 8 (the default on this part; not under a CU-masked stream
-   * or another partition mode): an XCD of the mask that received fewer workgroups than its chunk has tiles leaves them uncomputed.
-   * The re-arming workgroup adds the number of such tiles to tile_counters[12] (sticky, zeroed only by the caller): non-zero after a
-   * synchronisation = an incomplete launch. */
-  int32_t* tile_counters;
-  int32_t xcd_mask;
   /* non-zero: the out_bf16 shadow is written in the V2A_BF16_SPLIT layout, row m = [hi_0 .. hi_{N-1} | lo_0 .. lo_{N-1}] of the
    * (gamma-scaled, when norm_gamma is given) fp32 result, ld_out_bf16 >= 2 * N: the operand of a later split-bf16 GEMM without a
    * v2a_split_bf16 pass.  Likewise out_dtype = V2A_BF16_SPLIT (GEGLU epilogue only): out row m = [hi | lo] planes of the N/2
@@ -155,19 +142,6 @@ typedef struct v2a_gemm_args {
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
-/* Grouped form (ABI 7): nprob (1..3) independent problems behind ONE kernel launch -- the same Linear of the audio, text and frames
- * blocks of a layer (x3:1081-1137: A_i, T_i+1 and F_i+1 do not depend on each other), whose workgroups then share the chip inside one
- * launch instead of three kernels queueing on three streams.  All problems bf16 x bf16 -- all with plain or all with split (V2A_BF16_SPLIT)
- * operands -- with dense rows and 16-byte aligned epilogue operands; one tile_hint for the group (0 = by shape; plain operands: k + 1 =
- * tile configuration k of v2a_tuning.gemm_force_tile, supported 0, 1, 3, 6, 12, 14, 15; split operands: 1..5 as for v2a_gemm); the
- * epilogues of a group are either all STORE (to bf16; split operands: to fp32; RoPE allowed), all GEGLU (to bf16; split operands: to
- * hi | lo planes), or fp32 results with any mix of STORE / RESID / GATE_RESID (one kernel: an absent residual reads as 0, an absent gate as
- * 1 -- bit-identical to the separate epilogues).  Problems are dispatched longest K first.  The result of every problem equals its own
- * v2a_gemm call on the same tile form bit for bit (same K order per output element, same epilogue expressions).  Measured
- * (profiles/r04_group_probe.txt): a group takes 0.75x the sum of its members' single launches alone on the chip; inside the sampler the
- * three-queue schedule of single launches is faster than any chain of grouped launches, which is why the sampler's
- * default does not group. */
-int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_stream_t stream);
 /* sizeof(v2a_gemm_args) as the library was built: a binding checks its mirror of the struct against this */
 int v2a_gemm_args_size(void);
 
@@ -186,10 +160,7 @@ typedef struct v2a_tuning {
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t attn_one_group_from;    /* v2a_attention (bf16): launches with at least this many workgroups run one wave group per workgroup
                                    * instead of two that split the key tiles (0 = default 1536) */
-  int32_t reserved[1];            /* bit 6 (64): the 8-phase kernel with persistent workgroups (one per CU) that request their next tile's first K
-                                   * tile before the epilogue of the current one, instead of one workgroup per tile.  Off by default: +2.5 % per
-                                   * launch alone at 8 clips per GPU, -2.3 % in the sampler, where the static tile shares collide with the other
-                                   * streams' workgroups (profiles/r04_8phase_persistent_*.txt).  Other bits: probe builds only */
+  int32_t reserved[1];            /* probe builds only */
 } v2a_tuning;
 int v2a_set_tuning(const v2a_tuning* tuning);
 
@@ -235,21 +206,6 @@ int v2a_dwconv_silu_residual_norm(const float* x, float* out, const float* wt, c
                                   int32_t B, int32_t N, int32_t d, int32_t ksize,
                                   const int32_t* len, const v2a_dwconv_norm* norm, v2a_stream_t stream);
 
-/* Grouped form (ABI 7): up to three convolutions -- the audio, text and frames blocks of one layer, x3:1082,1097,1122 -- as ONE launch
- * while a single one cannot fill the chip (larger launches run one after another inside the call).  Same B, N, kernel size and length
- * array; per problem its tensors, width and (all or none) the folded norm (`norm.out_bf16 == NULL`: none).  Results equal the separate
- * calls bit for bit. */
-typedef struct v2a_dwconv_args {
-  const float* x;
-  float* out;
-  const float* wt;
-  const float* bias;
-  int32_t d, reserved;
-  v2a_dwconv_norm norm;
-} v2a_dwconv_args;
-int v2a_dwconv_grouped(const v2a_dwconv_args* args, int32_t nprob, int32_t B, int32_t N, int32_t ksize, const int32_t* len,
-                       v2a_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------
  * Rotary embedding applied in place to `nheads` consecutive 64-wide heads of every row
  * (the q and k column blocks of the fused QKV GEMM output).
@@ -288,10 +244,6 @@ typedef struct v2a_attn_args {
 } v2a_attn_args;
 
 int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);
-/* Grouped form (ABI 7): the bf16 self-attention of up to three blocks (audio / text / frames, x3:1084,1099,1126) as one launch over the
- * heads of all problems; same B, Nq, Nk, scale, softclamp; per problem its tensors, strides, head count and length arrays. */
-int v2a_attention_grouped(const v2a_attn_args* args, int32_t nprob, v2a_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------
  * Cross-attention of the audio stream in ONE launch (ABI 6): the q-projection GEMM of v2a_gemm -- STORE epilogue with the optional
  * row_ssq consumer scale, bias and fused RoPE -- whose 64-token x one-head output tile never leaves the workgroup: it is the Q

@@ -21,9 +21,7 @@ SAMPLER_SHAPES = ["1564x3088x1024", "1564x3088x1280", "1564x1552x512", "1564x819
 
 
 def set_cfg(t):
-    if t == 26:                         # the 8-phase kernel with persistent workgroups + cross-tile prefetch (profiles/r04_8phase_persistent_*: there
-        _lib.set_tuning(force_tile=6, eight_phase=1, persistent_8phase=True)      # t6 WAS the persistent form and t26 one workgroup per tile)
-    elif t == 6:
+    if t == 6:
         _lib.set_tuning(force_tile=6, eight_phase=1)
     elif t == 7:
         _lib.set_tuning(force_tile=6, eight_phase=2)

@@ -13,10 +13,12 @@ run() {  # name timeout cmd...
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping"; exit 99; fi
   return $rc
 }
+# DT=bf16x3 (or fp32): the profile / trace steps run that compute mode and tag their outputs with it
+DTA=""; DTS=""; if [ -n "$DT" ]; then DTA="--dtype $DT"; DTS="_$DT"; fi
 for s in "$@"; do
   case $s in
-    trace) rm -rf /tmp/trace; TAILN=3 run trace 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace -- python bench.py --steps 1 --warmup 1 --cfm-steps 8 --no-cpu-baseline --no-roofline --no-batched --no-parity-mode --no-configs --no-video2roll --no-vocoder
-           python scripts/timeline_summary.py /tmp/trace > gpurun_out/timeline.txt 2>&1; tail -n 90 gpurun_out/timeline.txt ;;
+    trace) rm -rf /tmp/trace; TAILN=3 run trace$DTS 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace -- python bench.py $DTA ${TRACE_EXTRA:-} --steps 1 --warmup 1 --cfm-steps 8 --no-cpu-baseline --no-roofline --no-batched --no-parity-mode --no-configs --no-video2roll --no-vocoder
+           python scripts/timeline_summary.py /tmp/trace > gpurun_out/timeline$DTS${TRACE_TAG:-}.txt 2>&1; tail -n ${TL_TAIL:-90} gpurun_out/timeline$DTS${TRACE_TAG:-}.txt ;;
     side) SW=${SIDE_SWEEP:-"-1:-1 0:-1 5:-1 6:-1 0:0 6:0"}
          for v in $SW; do
            st=${v%%:*}; mt=${v##*:}
@@ -41,29 +43,12 @@ for s in "$@"; do
     k8p) run k8p 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "8phase" ;;
     probe) TAILN=40 run probe 600 python scripts/gemm_probe.py ${PROBE_ARGS:-} ;;
     probe_geglu) TAILN=40 run probe_geglu 600 python scripts/gemm_probe.py --epi geglu 1564x8192x1024 1564x10240x1280 1564x4096x512 12512x8192x1024 ;;
-    gtiles) for v in ${GT_SWEEP:-"_" "qkv=13" "ff1=1" "ff2=15,out=15,cross=15" "_"}; do
-           a=""; [ "$v" != "_" ] && a="--group-tiles $v"
-           TAILN=0 run gt_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${GT_EXTRA:-}
-           echo "--- group tiles [$v] ${GT_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/gt_x.log | head -1)"
-         done ;;
-    chains) for v in ${CH_SWEEP:-"atf" "a|tf" "af|t" "a|t|f" "_"}; do
-           a="--chains $v"; [ "$v" = "_" ] && a="--no-grouped"
-           TAILN=0 run ch_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a ${CH_EXTRA:-}
-           echo "--- chains [$v] ${CH_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/ch_x.log | head -1)"
-         done ;;
     x3qkv) for v in ${X3_SWEEP:-"_" "a.qkv=5,t.qkv=5" "a.qkv=5,t.qkv=5,f.qkv=5" "_"}; do
            a=""; [ "$v" != "_" ] && a="--side-tiles $v"
            TAILN=0 run x3_x 300 python bench.py --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a
            echo "--- bf16x3 split tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/x3_x.log | head -1)"
          done ;;
-    persab) for v in "" "--persistent" "" "--persistent"; do
-           TAILN=0 run pa_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v ${PA_EXTRA:-}
-           echo "--- [$v] ${PA_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/pa_x.log | head -1) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/pa_x.log | head -1)"
-         done ;;
     soak) TAILN=12 run soak 1100 python scripts/probes/soak_probe.py ;;
-    gprobe) TAILN=60 run gprobe 600 python scripts/group_probe.py ${GP_ARGS:-} ;;
-    schedtests) TAILN=15 run schedtests 900 python -m pytest tests/test_grouped_gpu.py tests/test_sampler_gpu.py tests/test_full_shape_gpu.py -q -m gpu --tb=short -k "grouped" ;;
-    grouped) TAILN=25 run grouped 600 python -m pytest tests/test_grouped_gpu.py -q -m gpu --tb=short ;;
     kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x --tb=short ;;
     kernels_all) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=line ;;
     sampler) run sampler 600 python -m pytest tests/test_sampler_gpu.py -q -m gpu -x --tb=short -s ;;
@@ -150,14 +135,14 @@ for s in "$@"; do
            TAILN=0 run big_$t 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --clips-per-gpu 8
            echo "--- big $t B=8: $(grep -E 'timed' gpurun_out/big_$t.log)"
          done; unset V2A_GEMM_BIG ;;
-    prof) rm -rf /tmp/prof; run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
-          mkdir -p gpurun_out/prof; cp /tmp/prof/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_multistream.csv ;;
-    prof1) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
-          mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
-    prof8) rm -rf /tmp/prof8; run prof8 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -- python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
-          mkdir -p gpurun_out/prof; cp /tmp/prof8/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_8clips.csv ;;
-    prof8s) rm -rf /tmp/prof8s; run prof8s 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8s -- python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --single-stream --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
-          mkdir -p gpurun_out/prof; cp /tmp/prof8s/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_8clips_singlestream.csv ;;
+    prof) rm -rf /tmp/prof; run prof$DTS 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py $DTA --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+          mkdir -p gpurun_out/prof; cp /tmp/prof/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats${DTS}_multistream.csv ;;
+    prof1) rm -rf /tmp/prof1; run prof1$DTS 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py $DTA --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+          mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats${DTS}_singlestream.csv ;;
+    prof8) rm -rf /tmp/prof8; run prof8$DTS 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8 -- python bench.py $DTA --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+          mkdir -p gpurun_out/prof; cp /tmp/prof8/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats${DTS}_8clips.csv ;;
+    prof8s) rm -rf /tmp/prof8s; run prof8s$DTS 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof8s -- python bench.py $DTA --steps 2 --warmup 1 --clips-per-gpu 8 --single-stream --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
+          mkdir -p gpurun_out/prof; cp /tmp/prof8s/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats${DTS}_8clips_singlestream.csv ;;
     prof1_old) rm -rf /tmp/prof1; run prof1 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --single-stream --no-batched --no-video2roll --no-vocoder
           mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
     prof_v2r) rm -rf /tmp/profv; run prof_v2r 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profv -- python bench.py --steps 1 --warmup 0 --cfm-steps 4 --no-cpu-baseline --no-roofline --no-batched

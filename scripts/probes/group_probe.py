@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Time the sampler's GROUPED launches (v2a_gemm_grouped / v2a_attention_grouped / v2a_dwconv_grouped) stand-alone, per group and per
+"""[Round-5 note: grouped launches (ABI 7) left the library with ABI 8; this probe runs against commit 88e6ef7 (round 4) and is kept for its record under profiles/.]
+Time the sampler's GROUPED launches (v2a_gemm_grouped / v2a_attention_grouped / v2a_dwconv_grouped) stand-alone, per group and per
 tile shape, each inside a hipGraph of back-to-back launches on random data (interleaved rounds, best of 5).  One clip of the shipped
 widths unless --clips says otherwise: M = 2 * clips * 782 rows, streams a / t / f = 1024 / 1280 / 512 wide.
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""XCD-subset placement probe (tuning aid): time v2a_gemm launches alone and CONCURRENTLY on separate streams, each
+"""[Round-5 note: XCD-subset placement (v2a_gemm_args.xcd_mask, ABI 5-7) left the library with ABI 8; this probe runs against commit 88e6ef7 (round 4) and is kept for its record under profiles/.]
+XCD-subset placement probe (tuning aid): time v2a_gemm launches alone and CONCURRENTLY on separate streams, each
 launch optionally confined to a subset of the 8 XCDs (v2a_gemm_args.xcd_mask) with a chosen tile shape.
 
 A group is a '+'-joined list of specs  MxNxK[:tile[:mask[:epi]]]  (tile = tile_hint - 1 of v2a_gemm: 0 128x256, 1 128x128,

@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_abi_version_and_error_string(lib):
     L = lib.lib()
-    assert L.v2a_abi_version() == lib.ABI_VERSION == 7
+    assert L.v2a_abi_version() == lib.ABI_VERSION == 8
     g = lib.GemmArgs()
     g.nseg = 5
     assert L.v2a_gemm(ctypes.byref(g), None) == -1                 # V2A_ERR_ARG, before any HIP call

@@ -53,19 +53,43 @@ def test_scaling_reference_field(bench):
 
 
 def test_summary_fields_pick_the_parity_qualified_mode(bench):
-    mk = lambda v, e, ok: {"mel_frames_per_s": v, "ms_per_step": 750e3 / v, "steps": 20, "warmup": 5, "max_abs_delta_mel": e,
-                           "max_abs_delta_mel_over_grid": e, "meets_1e-3": ok}
-    res = {"dtype": "bf16", "parity_mode": {"fp32": mk(987.0, 9e-6, True), "bf16x3": mk(2799.0, 9e-5, True), "bf16": mk(5757.0, 0.049, False)},
-           "batched": {"mel_frames_per_s": 8847.0, "ms_per_step": 678.2,
-                       "roofline": {"all_gemm_frac": 0.309, "kernels": {"gemm<bf16,a_bf16,geglu,bf16,8ph>": {"tflops": 947.0, "share": 0.3},
-                                                                         "gemm<bf16,a_bf16,store,bf16,8ph>": {"tflops": 585.0, "share": 0.1}}}},
-           "roofline": {"hbm": {"clips_8": {"rmsnorm": {"frac": 0.495}}}}}
+    mk = lambda v, e, ok, **x: {"mel_frames_per_s": v, "ms_per_step": 750e3 / v, "steps": 20, "warmup": 5, "max_abs_delta_mel": e,
+                                "max_abs_delta_mel_over_grid": e, "meets_1e-3": ok, **x}
+    pm = {"fp32": mk(987.0, 9e-6, True), "bf16x3": mk(2799.0, 9e-5, True, clips8_max_abs_delta_mel=9.5e-5, clips8_mel_frames_per_s=3200.0),
+          "bf16": mk(5757.0, 0.049, False, clips8_max_abs_delta_mel=0.05, clips8_mel_frames_per_s=8300.0)}
+    batched = {"mel_frames_per_s": 3210.0, "ms_per_step": 1869.0,
+               "roofline": {"all_gemm_frac": 0.12, "all_gemm_frac_mfma_issued": 0.36,
+                            "kernels": {"gemm<bf16,a_split,geglu,bf16>": {"tflops": 380.0, "tflops_mfma_issued": 1140.0, "share": 0.3},
+                                        "gemm<bf16,a_split,store,f32,tile4>": {"tflops": 195.0, "tflops_mfma_issued": 585.0, "share": 0.1}}}}
+    # the headline is the parity-qualified mode: its parity and the fast bf16 mode's figures travel as scalars inside `roofline`
+    res = {"dtype": "bf16x3", "parity_mode": pm, "batched": batched, "roofline": {"hbm": {"clips_8": {"rmsnorm": {"frac": 0.495}}}}}
     out = bench.summary_fields(res)
-    pq = out["parity_qualified"]
-    assert pq["mode"] == "bf16x3" and pq["mel_frames_per_s"] == 2799.0 and pq["max_abs_delta_mel_over_grid"] < 1e-3 and "OUTSIDE" in pq["note"]
-    assert out["n1_8clips_mel_frames_per_s"] == 8847.0
-    assert list(out)[-1] == "summary" and out["summary"]["batched_8clips"]["frac_geglu"] == round(947.0 / 2500.0, 4)
-    assert res["roofline"]["clips8_frac_qkv_store_bf16"] == round(585.0 / 2500.0, 4) and out["summary"]["hbm_clips_8"] == {"rmsnorm": {"live": 0.495, "rocprof": None}}
+    pq, roof = out["parity_qualified"], res["roofline"]
+    assert pq["mode"] == "bf16x3" and pq["mel_frames_per_s"] == 2799.0 and pq["max_abs_delta_mel_over_grid"] < 1e-3 and "inside" in pq["note"]
+    assert roof["parity_max_abs_delta_mel_over_grid"] == 9e-5 and roof["parity_meets_1e-3"] is True and roof["clips8_parity_max_abs_delta_mel"] == 9.5e-5
+    assert roof["fast_bf16_mel_frames_per_s"] == 5757.0 and roof["fast_bf16_max_abs_delta_mel"] == 0.049 and roof["clips8_fast_bf16_mel_frames_per_s"] == 8300.0
+    assert roof["clips8_parity_qualified_mel_frames_per_s"] == 3210.0 and roof["clips8_mode"] == "bf16x3"
+    assert out["n1_8clips_mel_frames_per_s"] == 3210.0
+    assert list(out)[-1] == "summary" and out["summary"]["batched_8clips"]["frac_geglu"] == round(380.0 / 2500.0, 4)
+    assert out["summary"]["batched_8clips"]["frac_geglu_mfma_issued"] == round(1140.0 / 2500.0, 4)
+    assert roof["clips8_frac_qkv_store"] == round(195.0 / 2500.0, 4) and roof["clips8_frac_qkv_store_mfma_issued"] == round(585.0 / 2500.0, 4)
+    assert out["summary"]["hbm_clips_8"] == {"rmsnorm": {"live": 0.495, "rocprof": None}}
+    # a bf16 headline (--dtype bf16) is flagged as OUTSIDE the tolerance and gets no parity-qualified 8-clip scalar
+    res2 = {"dtype": "bf16", "parity_mode": pm, "batched": dict(batched), "roofline": {}}
+    out2 = bench.summary_fields(res2)
+    assert "OUTSIDE" in out2["parity_qualified"]["note"] and res2["roofline"]["parity_meets_1e-3"] is False
+    assert "clips8_parity_qualified_mel_frames_per_s" not in res2["roofline"]
+
+
+def test_dominant_reports_algorithmic_and_issued_fractions(bench):
+    """Split-operand (bf16x3) GEMM launches are profiled with the 6MNK flops the matrix cores run; the roofline's `achieved` / `frac` are
+    algorithmic (2MNK) and the issued figures sit beside them."""
+    agg = {"gemm<bf16,a_split,resid,f32>": {"launches": 30, "ms": 3.0, "flops": 30 * 6.0e9 * 3, "bytes": 1e9},
+           "gemm<f32,a_f32,store,f32>": {"launches": 3, "ms": 0.1, "flops": 1e9, "bytes": 1e6}, "attention<bf16x3>": {"launches": 3, "ms": 9.0, "flops": 1e9, "bytes": 1}}
+    k, dom, rec = bench._dominant(agg, 3, "test", bench.ROCPROF_STATS)
+    assert k == "gemm<bf16,a_split,resid,f32>" and rec["launches_per_eval"] == 10 and rec["gflop_per_launch"] == 6.0
+    assert abs(rec["achieved"] - 60.0) < 1e-6 and abs(rec["achieved_mfma_issued"] - 180.0) < 1e-6
+    assert abs(rec["frac"] * 3 - rec["frac_mfma_issued"]) < 2e-4 and rec["all_gemm_frac_mfma_issued"] > rec["all_gemm_frac"]
 
 
 def test_rocprof_hbm_block_finds_the_memory_bound_kernels(bench):

@@ -16,7 +16,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "video-to-audio-and-piano-rp_amd", "csrc", "build")
-SOURCES = ("gemm", "gemm_8phase", "rowops", "attention", "conv", "vocoder", "qproj_xattn", "grouped")
+SOURCES = ("gemm", "gemm_8phase", "rowops", "attention", "conv", "vocoder", "qproj_xattn")
 
 
 @pytest.fixture(scope="module")
@@ -67,10 +67,8 @@ KNOWN_SPILLS = ("gemm_bf16_dma_kernelILi0EfLi256ELi256E", "gemm_bf16_dma_kernelI
                 "gemm_bf16_dma_kernelILi2EDF16bLi256ELi256E", "gemm_bf16_dma_kernelILi3EfLi256ELi256E", "gemm_bf16_dma_kernelILi4EfLi256ELi256E")
 
 
-# the persistent 8-phase kernel (round 4): its tile loop keeps a dozen values live across the K loop and the epilogue sits at the edge of the
-# register file; the allocator parks up to ~40 registers in scratch AROUND the K loop (a few stores and reloads per 256x256 tile).  Allowed
-# there up to this many bytes per lane -- and never between the first and the last MFMA of any kernel (checked below for every kernel).
-SCRATCH_ALLOWED = {"gemm_bf16_8ph_kernel": 192}
+# per-kernel scratch allowances (bytes per lane): none -- no kernel on any path but KNOWN_SPILLS may touch scratch
+SCRATCH_ALLOWED = {}
 
 
 def test_no_scratch_spills(listings):

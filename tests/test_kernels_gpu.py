@@ -331,32 +331,6 @@ def test_gemm_gate_resid_and_sigmoid(L):
     torch.testing.assert_close(xd.cpu(), ref, atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("mask", [0x0F, 0xF0, 0x03, 0x81, 0x1FF])
-@pytest.mark.parametrize("tile", [3, 1, 12])
-def test_gemm_xcd_mask_placement(L, mask, tile):
-    """v2a_gemm_args.xcd_mask: a launch confined to a subset of the XCDs (workgroups read HW_REG_XCC_ID and claim the tiles of their
-    XCD's chunk through tile_counters; 0x1FF = all eight XCDs through the claim path).  Which workgroup computes a tile depends on the
-    dispatch, the result does not: bit-equal to the default placement, and the last workgroup re-arms the counters -- all sixteen words
-    zero afterwards, word 12 included: it counts tiles an XCD of the mask left unclaimed (an incomplete launch)."""
-    M, N, K = 1564, 1024, 1024
-    g = _g(mask + tile)
-    a = (torch.randn(M, K, generator=g) * 0.5).to(DEV, torch.bfloat16)
-    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV, torch.bfloat16)
-    res = torch.randn(M, N, generator=g).to(DEV)
-    ref, out = torch.empty(M, N, device=DEV), torch.full((M, N), float("nan"), device=DEV)
-    ctr = torch.zeros(16, dtype=torch.int32, device=DEV)
-    L.gemm([(a, K, K)], w, ref, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, resid=res, tile_hint=tile + 1)
-    for rep in range(3):                                   # the same counters serve consecutive launches on a stream
-        out.fill_(float("nan"))
-        L.gemm([(a, K, K)], w, out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, resid=res, tile_hint=tile + 1,
-               xcd_mask=mask, tile_counters=ctr)
-        torch.cuda.synchronize()
-        assert torch.equal(out, ref), (mask, tile, rep)
-        assert bool((ctr == 0).all()), ctr
-    with pytest.raises(L.V2AError, match="tile_counters"):
-        L.gemm([(a, K, K)], w, out, M=M, N=N, compute=L.BF16, epilogue=L.EPI_RESID, resid=res, xcd_mask=0x0F)
-
-
 def test_gemm_rejects_bad_args(L):
     a = torch.zeros(4, 40, device=DEV)
     w = torch.zeros(16, 40, device=DEV)
@@ -719,10 +693,8 @@ def _split_planes(x):
 def test_gemm_split_native(L, hint, epi, M, N, ks):
     """v2a_gemm with a_dtype V2A_BF16_SPLIT: A segments as [hi | lo] rows, W as [W_hi | W_lo], acc = A_lo W_hi + A_hi W_lo + A_hi W_hi
     in ONE launch over up to three logical K segments (TextAudioCrossCondition's pack, x3:693-700; hint 5 = the phase-interleaved
-    256x256 kernel on the segments [A_hi | A_hi | A_lo], one logical segment only), every epilogue of the bf16x3 mode: fp32 store, residual + split (hi | lo) shadow, gated residual + folded-norm producer with a split shadow, GEGLU with
+    256x256 kernel on three passes over the logical K -- hi x hi, hi x lo, lo x hi -- each over all segments), every epilogue of the bf16x3 mode: fp32 store, residual + split (hi | lo) shadow, gated residual + folded-norm producer with a split shadow, GEGLU with
     split output.  Against the fp64 product: ~1e-5 relative (three bf16 MFMA products per fp32 product)."""
-    if hint == 5 and len(ks) > 1:
-        pytest.skip("the 8-phase form takes one logical segment")
     g = _g(M + N + len(ks))
     K = sum(ks)
     a = [torch.randn(M, k, generator=g) for k in ks]

@@ -370,32 +370,6 @@ def test_plan_cache_and_buckets(small, mode):
     assert torch.equal(y, outs["short"]) and exact.graph_captures == 5             # "short" was used after "long": still cached
 
 
-@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
-@pytest.mark.parametrize("ragged", [False, True])
-def test_grouped_schedule_equals_three_streams(small, ragged, mode):
-    """bf16 and bf16x3 modes: the single chain of grouped launches (one launch per op for the audio block of layer i and the text / frames blocks of
-    layer i+1: v2a_gemm_grouped, v2a_attention_grouped, v2a_dwconv_grouped) against the three-stream schedule of single launches.  Every
-    problem of a group runs the same kernel arithmetic as its own launch, so the sampled latents are equal bit for bit -- with and
-    without the hipGraph, ragged durations and a dropped prompt included."""
-    i = small["inp"]
-    kw = dict(steps=5, cfg_strength=2.0, remove_parallel_component=False, return_raw_output=True)
-    if ragged:
-        kw.update(duration=torch.tensor([40, 29]), lens=torch.tensor([40, 29]), video_drop_prompt=[False, True])
-    outs = {}
-    for chains in ("atf", "a|tf", "af|t", "a|t|f", None):       # None: forward()'s three streams of single launches
-        for graph in (True, False):
-            m = make_model(small["cfg"], small["P"], mode, use_graph=graph)
-            m.engine().grouped = chains is not None
-            if chains:
-                m.engine().chains = tuple(tuple(ch) for ch in chains.split("|"))
-            outs[(chains, graph)] = m.sample(torch.zeros(2, 40, 16), y0=i["y0"], **_kw(i), **kw)
-            assert m.engine()._use_grouped() == (chains is not None)
-    ref = outs[(None, False)]
-    assert torch.isfinite(ref).all()
-    for k, v in outs.items():
-        assert torch.equal(v, ref), (k, float((v - ref).abs().max()))
-
-
 def test_buckets_with_remove_parallel_component(small):
     """remove_parallel_component=True (the default of sample(), x3:2134): the projection's sums run over the call's own (b, n, C) frames
     (x3:162-173).  A bucketed plan pads n behind them -- rows whose prediction is not zero -- so the reduction stops at the device-side

@@ -45,7 +45,7 @@ class GemmArgs(C.Structure):
         ("norm_switch_row", C.c_int32), ("norm_switch_offset", C.c_int32),
         ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64),
         ("row_ssq", C.c_void_p), ("ld_row_ssq", C.c_int64), ("row_ssq_parts", C.c_int32), ("row_norm_dim", C.c_int32),
-        ("tile_counters", C.c_void_p), ("xcd_mask", C.c_int32), ("out_bf16_split", C.c_int32),
+        ("out_bf16_split", C.c_int32),
     ]
 
 
@@ -54,12 +54,6 @@ class DwconvNorm(C.Structure):
     _fields_ = [("out_bf16", C.c_void_p), ("ld_out_bf16", C.c_int64), ("norm_gamma", C.c_void_p), ("step", C.c_void_p),
                 ("norm_step_stride", C.c_int64), ("norm_batch_stride", C.c_int64), ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64),
                 ("split", C.c_int32), ("reserved", C.c_int32)]
-
-
-class DwconvArgs(C.Structure):
-    """Mirror of `v2a_dwconv_args`: one problem of v2a_dwconv_grouped."""
-    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("wt", C.c_void_p), ("bias", C.c_void_p), ("d", C.c_int32), ("reserved", C.c_int32),
-                ("norm", DwconvNorm)]
 
 
 class Tuning(C.Structure):
@@ -90,7 +84,7 @@ class RollHeadArgs(C.Structure):
 
 
 EXPORTS = [
-    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_grouped", "v2a_attention_grouped", "v2a_dwconv_grouped", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual", "v2a_dwconv_silu_residual_norm",
+    "v2a_abi_version", "v2a_last_error", "v2a_gemm", "v2a_gemm_args_size", "v2a_set_tuning", "v2a_rmsnorm", "v2a_dwconv_silu_residual", "v2a_dwconv_silu_residual_norm",
     "v2a_rope_inplace", "v2a_attention", "v2a_qproj_xattn", "v2a_linear_small", "v2a_fill_registers", "v2a_time_cond",
     "v2a_apg_reduce", "v2a_cfg_euler", "v2a_step_advance", "v2a_cast_bf16", "v2a_split_bf16",
     "v2a_im2col", "v2a_frames_pack", "v2a_pool2d", "v2a_roll_head", "v2a_roll_expand",
@@ -112,7 +106,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-ABI_VERSION = 7          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
+ABI_VERSION = 8          # what v2a_abi_version() of this source tree returns (csrc/rowops.hip)
 
 
 def _declare(lib):
@@ -120,9 +114,6 @@ def _declare(lib):
     lib.v2a_abi_version.restype = C.c_int
     lib.v2a_last_error.restype = C.c_char_p
     lib.v2a_gemm.argtypes = [C.POINTER(GemmArgs), vp]
-    lib.v2a_gemm_grouped.argtypes = [C.POINTER(GemmArgs), i32, vp]
-    lib.v2a_attention_grouped.argtypes = [C.POINTER(AttnArgs), i32, vp]
-    lib.v2a_dwconv_grouped.argtypes = [C.POINTER(DwconvArgs), i32, i32, i32, i32, vp, vp]
     lib.v2a_gemm_args_size.restype = C.c_int
     lib.v2a_set_tuning.argtypes = [C.POINTER(Tuning)]
     lib.v2a_attention.argtypes = [C.POINTER(AttnArgs), vp]
@@ -171,15 +162,14 @@ def lib():
 
 
 def set_tuning(force_tile: int = -1, k_rotation: bool = False, eight_phase: int | None = None, eight_phase_min_tiles: int = 0,
-               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0, persistent_8phase: bool = False):
-    """Tile-selection overrides (A/B measurements); `set_tuning()` restores the library defaults.
-    persistent_8phase=True: the 8-phase GEMM kernel with persistent workgroups and cross-tile prefetch (off by default, v2a_tuning.reserved)."""
+               dwconv_rows_per_wave: int = 0, xcd_order_1x8: bool = False, attn_one_group_from: int = 0, reserved: int = 0):
+    """Tile-selection overrides (A/B measurements); `set_tuning()` restores the library defaults.  `reserved`: probe builds only."""
     if (force_tile == -1 and not k_rotation and eight_phase is None and eight_phase_min_tiles == 0 and dwconv_rows_per_wave == 0
-            and not xcd_order_1x8 and attn_one_group_from == 0 and not persistent_8phase):
+            and not xcd_order_1x8 and attn_one_group_from == 0 and not reserved):
         check(lib().v2a_set_tuning(None))
         return
     t = Tuning(force_tile, 1 if k_rotation else 0, 1 if eight_phase is None else eight_phase, eight_phase_min_tiles, dwconv_rows_per_wave,
-               1 if xcd_order_1x8 else 0, attn_one_group_from, (C.c_int32 * 1)(64 if persistent_8phase else 0))
+               1 if xcd_order_1x8 else 0, attn_one_group_from, (C.c_int32 * 1)(reserved))
     check(lib().v2a_set_tuning(C.byref(t)))
 
 
@@ -295,36 +285,12 @@ def gemm(a_segs, w, out, **kw):
     _launch(key, flops, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
 
 
-def gemm_grouped(built, tile_hint=0):
-    """built: 1..3 results of gemm_args -- independent problems run as ONE launch (v2a_gemm_grouped): the same Linear of the audio,
-    text and frames blocks of a layer.  tile_hint applies to the whole group (0 = by shape)."""
-    n = len(built)
-    if n == 1:              # one problem = a plain v2a_gemm launch (and its profiler class)
-        g, key, flops, nbytes = built[0]
-        g.tile_hint = tile_hint if g.compute_dtype == BF16 and g.a_dtype in (BF16, BF16_SPLIT) and g.epilogue != EPI_SIGMOID else 0
-        if g.tile_hint:
-            key = key.replace(">", ",tile%d>" % (g.tile_hint - 1), 1) if ",tile" not in key else key
-        _launch(key, flops, nbytes, lambda: lib().v2a_gemm(C.byref(g), stream_ptr()))
-        return
-    arr = (GemmArgs * n)()
-    for i, (g, _, _, _) in enumerate(built):
-        C.memmove(C.byref(arr[i]), C.byref(g), C.sizeof(GemmArgs))
-        arr[i].tile_hint = tile_hint
-    # the instantiation the group runs on: fp32 results go through the GATE_RESID epilogue whatever mix of STORE / RESID / GATE_RESID they are
-    f32 = built[0][0].out_dtype == F32
-    key = "gemm_grouped<bf16,a_bf16,%s,%s%s>" % ("gate_resid" if f32 else _EPI_NAMES[built[0][0].epilogue], "f32" if f32 else "bf16",
-                                                 ",tile%d" % (tile_hint - 1) if tile_hint else "")
-    if _prof is not None and _prof.shapes:
-        key += " " + "|".join(b[1].rsplit(" ", 1)[-1] for b in built)
-    _launch(key, sum(b[2] for b in built), sum(b[3] for b in built), lambda: lib().v2a_gemm_grouped(arr, n, stream_ptr()))
-
-
 def gemm_args(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, resid=None, gate=None,
          step=None, gate_step_stride=0, gate_batch_stride=0, rows_per_batch=0, ldo=None, ldr=None,
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
          a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0,
          norm_gamma=None, norm_step_stride=0, norm_batch_stride=0, norm_switch_row=0, norm_switch_offset=0, norm_ssq=None,
-         row_ssq=None, row_norm_dim=0, xcd_mask=0, tile_counters=None, out_bf16_split=False, a_split=False, out_split=False):
+         row_ssq=None, row_norm_dim=0, out_bf16_split=False, a_split=False, out_split=False):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype.
     a_split: the segments are V2A_BF16_SPLIT rows ([hi k | lo k], lda >= 2k) and w is [N][2K] = [W_hi | W_lo] (the bf16x3 mode's native
     GEMM: three MFMA products per fp32 product); out_split: GEGLU output as hi | lo planes; out_bf16_split: the shadow likewise.
@@ -369,7 +335,6 @@ def gemm_args(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, r
     g.ld_row_ssq = row_ssq.stride(-2) if row_ssq is not None else 0
     g.row_ssq_parts = row_norm_dim // 32 if row_ssq is not None else 0
     g.row_norm_dim = row_norm_dim
-    g.tile_counters, g.xcd_mask = _p(tile_counters), xcd_mask
     g.out_bf16_split = 1 if out_bf16_split else 0
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else ("a_split" if a_split else "a_bf16"),
@@ -409,24 +374,6 @@ def _dwconv_norm(norm, d):
     return n
 
 
-def dwconv_grouped(probs, *, B, N, ksize, lens=None):
-    """probs: 1..3 dicts(x, out, wt, bias, d, norm=None or the dict of dwconv()) -- the convolutions of the audio / text / frames blocks
-    of a layer as one launch (v2a_dwconv_grouped)."""
-    n = len(probs)
-    if n == 1:              # one problem = the plain launch (and its profiler class)
-        q = probs[0]
-        return dwconv(q["x"], q["out"], q["wt"], q["bias"], B=B, N=N, d=q["d"], ksize=ksize, lens=lens, norm=q.get("norm"))
-    arr = (DwconvArgs * n)()
-    for i, q in enumerate(probs):
-        arr[i].x, arr[i].out, arr[i].wt, arr[i].bias, arr[i].d = q["x"].data_ptr(), q["out"].data_ptr(), q["wt"].data_ptr(), q["bias"].data_ptr(), q["d"]
-        if q.get("norm") is not None:
-            arr[i].norm = _dwconv_norm(q["norm"], q["d"])
-    dsum = sum(q["d"] for q in probs)
-    with_norm = probs[0].get("norm") is not None
-    _launch("dwconv_grouped+norm" if with_norm else "dwconv_grouped", 2.0 * B * N * dsum * ksize, B * N * dsum * (10 if with_norm else 8),
-            lambda: lib().v2a_dwconv_grouped(arr, n, B, N, ksize, _p(lens), stream_ptr()))
-
-
 def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm=None):
     """norm = dict(out_bf16, gamma, ssq, step=None, step_stride=0, batch_stride=0): the RMSNorm after the conv folded in."""
     if norm is None:
@@ -450,18 +397,6 @@ def attention(q, k, v, gate, out, **kw):
     """q,k,v,gate,out: integer device addresses (views into fused buffers); one v2a_attention launch."""
     a, key, flops, nbytes = attention_args(q, k, v, gate, out, **kw)
     _launch(key, flops, nbytes, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
-
-
-def attention_grouped(built):
-    """built: 1..3 results of attention_args (bf16, same B / Nq / Nk / scale / softclamp): one launch over the heads of all of them."""
-    n = len(built)
-    if n == 1:
-        a, key, flops, nbytes = built[0]
-        return _launch(key, flops, nbytes, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
-    arr = (AttnArgs * n)()
-    for i, (a, _, _, _) in enumerate(built):
-        C.memmove(C.byref(arr[i]), C.byref(a), C.sizeof(AttnArgs))
-    _launch("attention_grouped<bf16>", sum(b[2] for b in built), sum(b[3] for b in built), lambda: lib().v2a_attention_grouped(arr, n, stream_ptr()))
 
 
 def attention_args(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype, out_split=False):

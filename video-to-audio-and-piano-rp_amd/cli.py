@@ -72,7 +72,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=64)                 # src/inference_v2a.py:183
     ap.add_argument("--cfg-strength", type=float, default=2.0)
     ap.add_argument("--frames", type=int, default=750, help="latent frames per clip (10 s)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16x3", "fp32"],
+    ap.add_argument("--dtype", default="bf16x3", choices=["bf16", "bf16x3", "fp32"],
                     help="bf16: fastest, |delta mel| ~ 5e-2 vs the fp32 reference arithmetic; bf16x3: split-bf16 products, < 1e-3 at ~0.4x the "
                          "bf16 speed; fp32: exact-fp32 MFMA, < 1e-3 at ~0.18x")
     ap.add_argument("--bucket-frames", type=int, default=64, help="pad plans to a multiple of this many latent frames (0 = exact shapes): "

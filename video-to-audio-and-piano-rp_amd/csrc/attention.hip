@@ -137,28 +137,9 @@ __global__ __launch_bounds__(64) void attn_rowlane_kernel(AttnParams p) {
 // logits are bounded by +-clamp, so with clamp * log2(e) <= 100 the weights 2^v lie in [2^-100, 2^100] and their sums over any
 // realistic key count stay far inside fp32 (and bf16 keeps fp32's exponent range for the P operand): the maximum, the
 // subtraction, the rescale of O and l per tile and two wave shuffles per tile disappear from a VALU-bound loop.
-// Grouped launch (v2a_attention_grouped): the self-attention of the audio, text and frames blocks of a layer as ONE launch -- blockIdx.y
-// runs over the heads of all problems (16 + 16 + 8), each head's workgroups take their problem's parameter block.  The problems share
-// B, Nq and the launch geometry; pointers, strides, head counts and lengths are per problem.
-constexpr int kAttnGroupMax = 3;
-struct AttnGroup {
-  int32_t nprob;
-  int32_t hstart[kAttnGroupMax + 1];
-  AttnParams p[kAttnGroupMax];
-};
-
-template <int NG, int CLAMP, bool GROUPED = false>
-__global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(const std::conditional_t<GROUPED, AttnGroup, AttnParams> arg) {
-  int h_ = blockIdx.y;
-  const AttnParams* pp_;
-  if constexpr (GROUPED) {
-    const int j = (h_ >= arg.hstart[1] ? 1 : 0) + (h_ >= arg.hstart[2] ? 1 : 0);
-    h_ -= arg.hstart[j];
-    pp_ = &arg.p[j];
-  } else {
-    pp_ = &arg;
-  }
-  const AttnParams& p = *pp_;
+template <int NG, int CLAMP>
+__global__ __launch_bounds__(256 * NG) void attn_mfma_kernel(const AttnParams p) {
+  const int h_ = blockIdx.y;
   constexpr int TK = 64;
   constexpr int K_ELEMS = TK * 64, V_ELEMS = TK * 64;     // both tiles row-major [key][64], 16-B chunks XOR-swizzled by (key & 7)
   constexpr int RING = 2 * (K_ELEMS + V_ELEMS);
@@ -408,18 +389,9 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
   }
 }
 
-template <int NG, int CLAMP, bool GROUPED = false>
-__global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const std::conditional_t<GROUPED, AttnGroup, AttnParams> arg) {
-  int h_ = blockIdx.y;
-  const AttnParams* pp_;
-  if constexpr (GROUPED) {      // grouped launch: the problem this head belongs to (see attn_mfma_kernel)
-    const int j = (h_ >= arg.hstart[1] ? 1 : 0) + (h_ >= arg.hstart[2] ? 1 : 0);
-    h_ -= arg.hstart[j];
-    pp_ = &arg.p[j];
-  } else {
-    pp_ = &arg;
-  }
-  const AttnParams& p = *pp_;
+template <int NG, int CLAMP>
+__global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnParams p) {
+  const int h_ = blockIdx.y;
   constexpr int TK = 64;
   constexpr int K_ELEMS = TK * 64, V_ELEMS = TK * 64;     // all four planes row-major [key][64], swizzled like the bf16 kernel's
   constexpr int STAGE = 2 * (K_ELEMS + V_ELEMS);          // Kh | Kl | Vh | Vl
@@ -925,16 +897,6 @@ int launch_attn_f32(const AttnParams& p, dim3 grid, hipStream_t s) {
 }
 
 template <int NG, int CLAMP>
-int launch_attn_split_grouped(const AttnGroup& g, dim3 grid, hipStream_t s) {
-  constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 64) * sizeof(bf16_t);
-  auto kern = attn_mfma_split_kernel<NG, CLAMP, true>;
-  static std::atomic<uint64_t> lds_set{0};
-  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_attention_grouped")) return rc;
-  hipLaunchKernelGGL(kern, grid, dim3(256 * NG), smem, s, g);
-  return V2A_OK;
-}
-
-template <int NG, int CLAMP>
 int launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 64) * sizeof(bf16_t);
   auto kern = attn_mfma_split_kernel<NG, CLAMP>;
@@ -1036,67 +998,4 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   }
   if (rc != V2A_OK) return rc;
   return v2a_check_launch("v2a_attention");
-}
-
-// The bf16 self-attention of up to three blocks in one launch (audio / text / frames streams of a layer): same B, Nq, Nk, scale and soft
-// clamp, per-problem tensors, strides, head counts and length arrays.  Same kernel, same arithmetic, same results as nprob v2a_attention calls.
-extern "C" int v2a_attention_grouped(const v2a_attn_args* args, int32_t nprob, v2a_stream_t stream) {
-  V2A_REQUIRE(args != nullptr && nprob >= 1 && nprob <= kAttnGroupMax, "v2a_attention_grouped: %d problems (1..%d)", nprob, kAttnGroupMax);
-  if (nprob == 1) return v2a_attention(args, stream);
-  AttnGroup g{};
-  g.nprob = nprob;
-  int htot = 0;
-  for (int j = 0; j < nprob; ++j) {
-    const v2a_attn_args* a = args + j;
-    V2A_REQUIRE(a->q && a->k && a->v && a->out && a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk > 0, "v2a_attention_grouped: problem %d: null tensor or empty shape", j);
-    V2A_REQUIRE((a->dtype == V2A_BF16 && !a->out_split) || (a->dtype == V2A_BF16_SPLIT && a->out_split), "v2a_attention_grouped: bf16 problems, or split-bf16 problems with split outputs (problem %d: dtype %d)", j, a->dtype);
-    V2A_REQUIRE(a->dtype == args[0].dtype, "v2a_attention_grouped: one dtype per group");
-    V2A_REQUIRE(a->B == args[0].B && a->Nq == args[0].Nq && a->Nk == args[0].Nk && a->scale == args[0].scale && a->softclamp == args[0].softclamp,
-                "v2a_attention_grouped: problem %d differs from problem 0 in B / Nq / Nk / scale / softclamp", j);
-    const int ev = a->dtype == V2A_BF16 ? 8 : 4;       // elements per 16 bytes of q / k / v (bf16, or fp32 in the split mode)
-    const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) == 0 && ((uintptr_t)a->out & 7) == 0 &&
-                         a->q_row_stride % ev == 0 && a->k_row_stride % ev == 0 && a->v_row_stride % ev == 0 &&
-                         a->q_batch_stride % ev == 0 && a->k_batch_stride % ev == 0 && a->v_batch_stride % ev == 0 &&
-                         a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0 &&
-                         (a->dtype == V2A_BF16 || a->out_row_stride >= 2 * (int64_t)a->H * 64);
-    V2A_REQUIRE(aligned, "v2a_attention_grouped: problem %d: head slices must be 16-byte aligned, output rows 8-byte aligned (split: 2 * H * 64 bf16 per row)", j);
-    AttnParams& p = g.p[j];
-    p.q = a->q; p.k = a->k; p.v = a->v; p.gate = a->gate; p.out = a->out;
-    p.qrs = a->q_row_stride; p.krs = a->k_row_stride; p.vrs = a->v_row_stride; p.grs = a->gate_row_stride; p.ors = a->out_row_stride;
-    p.qbs = a->q_batch_stride; p.kbs = a->k_batch_stride; p.vbs = a->v_batch_stride; p.gbs = a->gate_batch_stride; p.obs = a->out_batch_stride;
-    p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
-    p.kv_len = a->kv_len; p.q_len = a->q_len;
-    p.scale = a->scale; p.clamp = a->softclamp;
-    p.out_split = a->out_split ? 1 : 0;
-    p.dbg = v2a_detail::g_probe_dbg;
-    g.hstart[j] = htot;
-    htot += a->H;
-  }
-  for (int j = nprob; j <= kAttnGroupMax; ++j) g.hstart[j] = 0x7fffffff;
-  const v2a_attn_args* a = args;
-  hipStream_t s = (hipStream_t)stream;
-  const dim3 g64((a->Nq + 63) / 64, htot, a->B);
-  const int cl = attn_clamp_mode(a->softclamp, a->Nk);
-  // one or two wave groups per workgroup: what v2a_attention would pick for the LARGEST problem alone, so that a problem's result does
-  // not depend on what it is grouped with (the two-group form merges two partial sums: same value up to rounding, not bit for bit)
-  int hmax = 0;
-  for (int j = 0; j < nprob; ++j) hmax = args[j].H > hmax ? args[j].H : hmax;
-  if (a->dtype == V2A_BF16_SPLIT) {       // the bf16x3 mode's kernel: two wave groups whenever there is more than two key tiles, as v2a_attention
-    int rc;
-    if (a->Nk > 128) rc = cl == 2 ? launch_attn_split_grouped<2, 2>(g, g64, s) : (cl == 1 ? launch_attn_split_grouped<2, 1>(g, g64, s) : launch_attn_split_grouped<2, 0>(g, g64, s));
-    else rc = cl == 2 ? launch_attn_split_grouped<1, 2>(g, g64, s) : (cl == 1 ? launch_attn_split_grouped<1, 1>(g, g64, s) : launch_attn_split_grouped<1, 0>(g, g64, s));
-    if (rc != V2A_OK) return rc;
-    return v2a_check_launch("v2a_attention_grouped");
-  }
-  const bool split_kv = a->Nk > 128 && (int64_t)g64.x * hmax * g64.z < v2a_detail::g_attn_one_group_from;
-  if (split_kv) {
-    if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<2, 2, true>), g64, dim3(512), 0, s, g);
-    else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<2, 1, true>), g64, dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((attn_mfma_kernel<2, 0, true>), g64, dim3(512), 0, s, g);
-  } else {
-    if (cl == 2) hipLaunchKernelGGL((attn_mfma_kernel<1, 2, true>), g64, dim3(256), 0, s, g);
-    else if (cl == 1) hipLaunchKernelGGL((attn_mfma_kernel<1, 1, true>), g64, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((attn_mfma_kernel<1, 0, true>), g64, dim3(256), 0, s, g);
-  }
-  return v2a_check_launch("v2a_attention_grouped");
 }

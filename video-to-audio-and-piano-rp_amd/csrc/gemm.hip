@@ -190,21 +190,11 @@ __device__ __forceinline__ void ring_wait(int younger) {
 //   acc += A_lo W_hi + A_hi W_lo + A_hi W_hi   (fp32-grade product, relative error ~2^-16),
 // so a K step moves 2x the bytes of a bf16 step for 3x its flops -- where the three-segment form on the plain kernel
 // ([A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]) moved 3x the bytes and needed one launch per logical K segment.
-// GROUPED: the argument is a GemmGroup and the workgroup first picks its problem (gemm_common.h); everything after that is the
-// single-problem kernel on that problem's parameter block.
 // (Round 4 measured a software-pipelined form of the K loop -- the fragment reads of tile k + 1 issued behind the barrier of step k into a
 // second register set, landing under the MFMAs of tile k: 1-5 % SLOWER at equal occupancy, 16-27 % where the extra registers cost a
 // resident workgroup, profiles/r04_ring_pipe_probe.txt.  The exposed part of a K step is not the LDS read latency; the form is not kept.)
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false, bool GROUPED = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const std::conditional_t<GROUPED, v2a_detail::GemmGroup, GemmParams> arg) {
-  int bid_ = blockIdx.x;
-  const GemmParams* pp_;
-  if constexpr (GROUPED) pp_ = &group_pick(arg, bid_);
-  else pp_ = &arg;
-  const GemmParams& p = *pp_;
-  if constexpr (GROUPED) {
-    if (bid_ >= p.tiles_m * p.tiles_n) return;       // padding between the problems of a group (starts are multiples of 8)
-  }
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
@@ -222,54 +212,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const std
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 15, lq = lane >> 4;
 
-  const int tiles_n = p.tiles_n, tiles_m = p.tiles_m;
   int tm, tn;
-  if (p.tile_ctr) {
-    // XCD-subset placement: one lane asks which XCD the workgroup landed on; on an XCD of the mask it claims the next tile of that
-    // XCD's contiguous chunk of the rectangle order (chunk j of xcd_cnt for the j-th XCD of the mask), elsewhere -- or once the
-    // chunk is used up -- the workgroup leaves.  Which workgroup computes which tile depends on the placement, the result does not.
-    int* slot = reinterpret_cast<int*>(smem_raw + NST * STAGE_BYTES + BM * 4);
-    if (tid == 0) {
-      const int xcc = xcc_id();
-      int L = -1;
-      if ((p.xcd_mask >> xcc) & 1) {
-        const int j = __builtin_popcount(p.xcd_mask & ((1 << xcc) - 1));
-        const int nwg = tiles_m * tiles_n;
-        const int lo = (int)((int64_t)nwg * j / p.xcd_cnt), hi = (int)((int64_t)nwg * (j + 1) / p.xcd_cnt);
-        const int t = __hip_atomic_fetch_add(p.tile_ctr + 2 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lo + t < hi) L = lo + t;
-      }
-      // arrival count: the last workgroup to have claimed re-arms the counters for the next launch on them (the claim above has
-      // returned before the arrival is issued: the two go to different L2 channels)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int a = __hip_atomic_fetch_add(p.tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a == (int)gridDim.x - 1) {
-        // every workgroup of the launch has claimed: an XCD of the mask whose claims fell short of its chunk (the dispatcher did not deal
-        // workgroup i to XCD i % 8 -- a CU-masked stream, another partition mode) left tiles uncomputed.  That cannot be repaired from
-        // here; it is COUNTED in tile_counters[12] (sticky) so that the caller can tell an incomplete launch from a complete one.
-        const int nwg = tiles_m * tiles_n;
-        int j = 0, missing = 0;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          if ((p.xcd_mask >> x) & 1) {
-            const int lo = (int)((int64_t)nwg * j / p.xcd_cnt), hi = (int)((int64_t)nwg * (j + 1) / p.xcd_cnt);
-            if (p.tile_ctr[2 + x] < hi - lo) missing += hi - lo - p.tile_ctr[2 + x];
-            ++j;
-          }
-          p.tile_ctr[2 + x] = 0;
-        }
-        if (missing) p.tile_ctr[12] += missing;
-        p.tile_ctr[0] = 0;
-      }
-      *slot = L;
-    }
-    __syncthreads();
-    const int L = __builtin_amdgcn_readfirstlane(*slot);
-    if (L < 0) return;
-    tile_of_index(p, L, tm, tn);
-  } else {
-    tile_of_block(p, bid_, tm, tn);
-  }
+  tile_of_block(p, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4 acc[TM][TN];
@@ -499,12 +443,9 @@ int launch_dma(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
   v2a_detail::fill_tile_map(p, BM, BN);
   V2A_REQUIRE((int64_t)p.tiles_m * p.tiles_n < (1 << 24), "v2a_gemm: %d x %d tiles exceed the tile map", p.tiles_m, p.tiles_n);
-  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 * (S3 ? 2 : 1) + BM * 4 + 16;    // the ring + one row scale per tile row (folded RMSNorm) + the claimed tile
+  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 * (S3 ? 2 : 1) + BM * 4 + 16;    // the ring + one row scale per tile row (folded RMSNorm)
   static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
-  int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  // XCD-subset placement: workgroups are dealt round-robin over the 8 XCDs, so 8 * ceil(tiles / XCDs in the mask) of them put
-  // enough on every XCD of the mask to claim its chunk; the rest leave at once
-  if (p.tile_ctr) tiles = 8 * ((tiles + p.xcd_cnt - 1) / p.xcd_cnt);
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
   auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3>;
@@ -557,66 +498,11 @@ int dispatch_s3(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
   return v2a_fail(V2A_ERR_ARG, "v2a_gemm(split bf16): unsupported epilogue %d / out_dtype %d for this tile shape", a->epilogue, a->out_dtype);
 }
 
-// ---- grouped launches (v2a_gemm_grouped) -----------------------------------------------------------------------------------
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST, bool S3 = false>
-int launch_dma_grouped(v2a_detail::GemmGroup& g, hipStream_t s) {
-  int total = 0;
-  for (int j = 0; j < g.nprob; ++j) {
-    v2a_detail::fill_tile_map(g.p[j], BM, BN);
-    V2A_REQUIRE((int64_t)g.p[j].tiles_m * g.p[j].tiles_n < (1 << 24), "v2a_gemm_grouped: %d x %d tiles exceed the tile map", g.p[j].tiles_m, g.p[j].tiles_n);
-    g.start[j] = total;
-    total += (g.p[j].tiles_m * g.p[j].tiles_n + 7) / 8 * 8;
-  }
-  for (int j = g.nprob; j <= v2a_detail::kGroupMax; ++j) g.start[j] = 0x7fffffff;
-  g.total = total;
-  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 * (S3 ? 2 : 1) + BM * 4 + 16;
-  static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
-  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3, true>;
-  static std::atomic<uint64_t> lds_set{0};
-  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm_grouped(dma)")) return rc;
-  hipLaunchKernelGGL(kern, dim3(total), dim3(64 * WGM * WGN), smem, s, g);
-  return v2a_check_launch("v2a_gemm_grouped(dma)");
-}
-
-// epi: V2A_EPI_STORE (bf16 out), V2A_EPI_GEGLU (bf16 out) or V2A_EPI_GATE_RESID (fp32 out; problems without a gate / residual run
-// through it with the absent operands read as 1 / 0)
-template <int BM, int BN, int WGM, int WGN, int NST = 3>
-int dispatch_grouped(v2a_detail::GemmGroup& g, int epi, hipStream_t s) {
-  switch (epi) {
-    case V2A_EPI_STORE: return launch_dma_grouped<V2A_EPI_STORE, bf16_t, BM, BN, WGM, WGN, NST>(g, s);
-    case V2A_EPI_GEGLU:
-      if constexpr ((BN / WGN / 16) % 2 == 0) return launch_dma_grouped<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST>(g, s);
-      break;
-    case V2A_EPI_GATE_RESID: return launch_dma_grouped<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST>(g, s);
-  }
-  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped: epilogue %d on this tile shape", epi);
-}
-
-// split-bf16 operands (bf16x3 mode): STORE to fp32 (the [q | k | v | gate] rows stay fp32 there), GEGLU to hi | lo planes, fp32 residual family
-template <int BM, int BN, int WGM, int WGN, int NST>
-int dispatch_grouped_s3(v2a_detail::GemmGroup& g, int epi, hipStream_t s) {
-  switch (epi) {
-    case V2A_EPI_STORE: return launch_dma_grouped<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST, true>(g, s);
-    case V2A_EPI_GEGLU:
-      if constexpr ((BN / WGN / 16) % 2 == 0) return launch_dma_grouped<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST, true>(g, s);
-      break;
-    case V2A_EPI_GATE_RESID: return launch_dma_grouped<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST, true>(g, s);
-  }
-  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped(split bf16): epilogue %d on this tile shape", epi);
-}
-
-// split operands on the 8-phase kernel: three K segments [A_hi | A_hi | A_lo] against the weight row [W_hi | W_lo], the third segment
-// reading W_hi again (GemmParams::w_adj2)
-void split_as_three_segments(GemmParams& q) {
-  const int64_t k1 = q.kend[0];
-  const void* a0 = q.a[0];
-  q.nseg = 3;
-  q.a[0] = q.a[1] = a0;
-  q.a[2] = reinterpret_cast<const bf16_t*>(a0) + k1;
-  q.lda[1] = q.lda[2] = q.lda[0];
-  q.kend[0] = (int32_t)k1; q.kend[1] = (int32_t)(2 * k1); q.kend[2] = (int32_t)(3 * k1);
-  q.K = (int32_t)(3 * k1);
-  q.w_adj2 = -4 * k1;
+// split operands on the 8-phase kernel: three passes over the logical K -- A_hi x W_hi, A_hi x W_lo, A_lo x W_hi -- each over all logical
+// segments (GemmParams::s3_kl; the kernel derives plane and segment of every K tile)
+void split_as_three_passes(GemmParams& q) {
+  q.s3_kl = q.K;
+  q.K = 3 * q.K;
 }
 
 }  // namespace
@@ -630,7 +516,6 @@ v2a_detail::GemmTuning v2a_detail::g_gemm_tuning = kDefaultTuning;
 int v2a_detail::g_dwconv_rows_per_wave = 4;
 int v2a_detail::g_attn_one_group_from = 1536;
 int v2a_detail::g_probe_dbg = 0;       // v2a_tuning.reserved[0]: read by probe builds only
-int v2a_detail::g_8ph_persistent = 0;   // v2a_tuning.reserved[0] bit 6 switches it on (A/B: +2.5 % per launch alone, -2.3 % in the 8-clip sampler)
 int v2a_detail::g_dwconv_stream = 1;   // streaming depthwise conv for chip-filling launches (dwconv_rows_per_wave = -1 switches it off: A/B)
 
 extern "C" int v2a_gemm_args_size(void) { return (int)sizeof(v2a_gemm_args); }
@@ -642,7 +527,6 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
     v2a_detail::g_dwconv_stream = 1;
     v2a_detail::g_attn_one_group_from = 1536;
     v2a_detail::g_probe_dbg = 0;
-    v2a_detail::g_8ph_persistent = 0;
     return V2A_OK;
   }
   // every field is checked before any is assigned: a rejected call leaves the previous tuning whole
@@ -658,11 +542,10 @@ extern "C" int v2a_set_tuning(const v2a_tuning* t) {
                                t->gemm_8phase_min_tiles > 0 ? t->gemm_8phase_min_tiles : kDefaultTuning.min_tiles_8phase,
                                t->gemm_xcd_order_1x8 ? 0 : 1, t->reserved[0]};
   v2a_detail::g_probe_dbg = t->reserved[0];
-  v2a_detail::g_8ph_persistent = (t->reserved[0] & 64) ? 1 : 0;
   return V2A_OK;
 }
 
-// argument checks + the kernel parameter block of one problem (shared by v2a_gemm and v2a_gemm_grouped)
+// argument checks + the kernel parameter block
 static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
   V2A_REQUIRE(a != nullptr, "v2a_gemm: null args");
   V2A_REQUIRE(a->nseg >= 1 && a->nseg <= 3, "v2a_gemm: nseg=%d", a->nseg);
@@ -745,24 +628,6 @@ static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
     p.xcd_gm = best_gm;
     p.xcd_gn = 8 / best_gm;
   }
-  p.tile_ctr = nullptr;
-  if (a->xcd_mask && (a->xcd_mask & 0xFF) != 0xFF) {
-    V2A_REQUIRE(a->tile_counters != nullptr && ((uintptr_t)a->tile_counters & 3) == 0, "v2a_gemm: xcd_mask needs tile_counters (16 zeroed int32)");
-    p.tile_ctr = a->tile_counters;
-    p.xcd_mask = a->xcd_mask & 0xFF;
-    p.xcd_cnt = __builtin_popcount(p.xcd_mask);
-    // rectangles over the XCDs of the mask
-    const double ab = (double)a->M * K * 2, wb = (double)a->N * K * 2;
-    int best_gm = 1;
-    double best = ab * p.xcd_cnt + wb;
-    for (int gm = 2; gm <= p.xcd_cnt; ++gm) {
-      if (p.xcd_cnt % gm) continue;
-      const double c = ab * (p.xcd_cnt / gm) + wb * gm;
-      if (c < best * 0.95) { best = c; best_gm = gm; }
-    }
-    p.xcd_gm = best_gm;
-    p.xcd_gn = p.xcd_cnt / best_gm;
-  }
   p.a_rowoff = a->a_row_offset;
   p.a_koff = a->a_ktile_offset;
   p.o_rowoff = a->out_row_offset;
@@ -835,20 +700,20 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     // split-operand tile shapes (hi + lo planes double a stage): 1 = 64x64 (96 KB), 2 = 128x64 (144 KB), 3 = 128x128 with 8 waves and a
     // 2-deep ring (128 KB), 4 = 64x128 with 8 waves (144 KB)
     int cfg = a->tile_hint;
-    // wide outputs with enough 256x256 tiles: the phase-interleaved kernel on three K segments [A_hi | A_hi | A_lo] x [W_hi | W_lo | W_hi]
-    // (audio feed-forward at one clip: 76 us against 102 us on the best split ring tile; it re-reads A_hi and W_hi, but its K loop
-    // hides the operand stream behind the MFMAs).  One logical segment only; tile_hint 5 asks for it, 0 picks by shape.
-    const bool wide8 = a->nseg == 1 && tune.use_8phase && (cfg == 5 || (cfg == 0 && a->N >= 2048 && nt(256, 256) >= 150));
+    // the phase-interleaved 256x256 kernel on three passes over the logical K (hi x hi, hi x lo, lo x hi; it re-reads A_hi and W_hi, but
+    // its K loop hides the operand stream behind the MFMAs): wide outputs from 150 tiles (audio feed-forward at one clip: 76 us against
+    // 102 us on the best split ring tile) and -- round 5 -- narrow ones (512 < N < 2048, any number of logical segments) from 150 tiles,
+    // i.e. from ~6 clips per GPU: at 8 clips the 64x128 split ring ran them at 28 % of the MFMA peak (issued products) against 46 % here.
+    // tile_hint 5 asks for it, 0 picks by shape.
+    const bool wide8 = tune.use_8phase && (cfg == 5 || (cfg == 0 && a->N > 512 && nt(256, 256) >= 150));
     if (wide8) {
       GemmParams q = p;
-      const int64_t k1 = a->ka[0];
-      split_as_three_segments(q);
+      split_as_three_passes(q);
 #ifdef V2A_GEMM_PROBE
-      if (tune.dbg & 32) { q.nseg = 1; q.K = (int32_t)k1; }      // error attribution: hi x hi only
+      if (tune.dbg & 32) { q.s3_kl = 0; q.K = K; }      // error attribution: hi x hi only
 #endif
       return v2a_detail::launch_gemm_8phase(q, a->epilogue, a->out_dtype == V2A_BF16_SPLIT ? V2A_BF16 : a->out_dtype, s);
     }
-    V2A_REQUIRE(cfg != 5, "v2a_gemm: tile_hint 5 (8-phase) with split operands needs one segment");
     if (cfg == 0) {
       if (a->epilogue == V2A_EPI_GEGLU || a->N >= 2048) cfg = nt(128, 128) >= 200 ? 3 : 4;
       else cfg = nt(64, 128) >= 160 ? 4 : 1;
@@ -931,98 +796,4 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
     case 8: return dispatch_dma<64, 64, 2, 2, 6>(a, p, s);  // 4 waves,  96 KB: 6-deep ring, 1 workgroup/CU (<= 256 tiles)
     default: return dispatch_dma<64, 64, 2, 2>(a, p, s);    // 4 waves,  48 KB, 3 workgroups/CU
   }
-}
-
-// Up to three independent problems in one launch (the same op of the audio / text / frames blocks of a layer).
-extern "C" int v2a_gemm_grouped(const v2a_gemm_args* args, int32_t nprob, v2a_stream_t stream) {
-  V2A_REQUIRE(args != nullptr && nprob >= 1 && nprob <= v2a_detail::kGroupMax, "v2a_gemm_grouped: %d problems (1..%d)", nprob, v2a_detail::kGroupMax);
-  if (nprob == 1) return v2a_gemm(args, stream);
-  // the epilogue of the group: fp32 results with any mix of STORE / RESID / GATE_RESID (one instantiation: absent operands read as 0 / 1),
-  // or one epilogue and output dtype for all -- STORE (bf16; split operands: fp32) with RoPE, or GEGLU (bf16; split operands: hi | lo planes)
-  bool any_resid = false;
-  for (int j = 0; j < nprob; ++j) any_resid = any_resid || args[j].epilogue == V2A_EPI_RESID || args[j].epilogue == V2A_EPI_GATE_RESID;
-  const bool split = args[0].a_dtype == V2A_BF16_SPLIT;
-  const int epi = any_resid ? V2A_EPI_GATE_RESID : args[0].epilogue;
-  V2A_REQUIRE(epi == V2A_EPI_STORE || epi == V2A_EPI_GEGLU || epi == V2A_EPI_GATE_RESID, "v2a_gemm_grouped: epilogue %d", args[0].epilogue);
-  v2a_detail::GemmGroup g{};
-  g.nprob = nprob;
-  int order[v2a_detail::kGroupMax];
-  GemmParams tmp[v2a_detail::kGroupMax];
-  for (int j = 0; j < nprob; ++j) {
-    const v2a_gemm_args* a = args + j;
-    if (int rc = gemm_prepare(a, tmp[j])) return rc;
-    V2A_REQUIRE(a->compute_dtype == V2A_BF16 && a->a_dtype == (split ? V2A_BF16_SPLIT : V2A_BF16) && tmp[j].vec_epi && !a->a_row_offset && !a->out_row_offset &&
-                    !a->relu && !(a->xcd_mask && (a->xcd_mask & 0xFF) != 0xFF),
-                "v2a_gemm_grouped: problem %d must be bf16 x bf16 (all plain or all split operands) with dense rows and 16-byte aligned epilogue operands", j);
-    if (any_resid) {
-      V2A_REQUIRE(a->out_dtype == V2A_F32 && (a->epilogue == V2A_EPI_RESID || a->epilogue == V2A_EPI_GATE_RESID || a->epilogue == V2A_EPI_STORE) && !a->rope_table,
-                  "v2a_gemm_grouped: problem %d: fp32 STORE / RESID / GATE_RESID problems group together (epilogue %d)", j, a->epilogue);
-      if (a->epilogue == V2A_EPI_STORE) tmp[j].resid = nullptr;
-      if (a->epilogue != V2A_EPI_GATE_RESID) tmp[j].gate = nullptr;
-    } else {
-      const int want = epi == V2A_EPI_STORE ? (split ? V2A_F32 : V2A_BF16) : (split ? V2A_BF16_SPLIT : V2A_BF16);
-      V2A_REQUIRE(a->epilogue == epi && a->out_dtype == want, "v2a_gemm_grouped: problem %d: epilogue %d / out dtype %d differs from the group's (%d / %d)", j,
-                  a->epilogue, a->out_dtype, epi, want);
-    }
-    V2A_REQUIRE(a->tile_hint == args[0].tile_hint, "v2a_gemm_grouped: one tile_hint for the whole group");
-    order[j] = j;
-  }
-  // longest K first (stable): see GemmGroup
-  for (int i = 1; i < nprob; ++i)
-    for (int j = i; j > 0 && tmp[order[j]].K > tmp[order[j - 1]].K; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
-  for (int j = 0; j < nprob; ++j) g.p[j] = tmp[order[j]];
-  hipStream_t s = (hipStream_t)stream;
-  if (split) {
-    // split-operand tile shapes as for v2a_gemm: 1 = 64x64, 2 = 128x64, 3 = 128x128 (8 waves, 2-deep ring), 4 = 64x128 (8 waves), 5 = the
-    // 8-phase kernel on three K segments (one logical segment per problem); 0 = by shape
-    int cfg = args[0].tile_hint;
-    V2A_REQUIRE(cfg >= 0 && cfg <= 5, "v2a_gemm_grouped: tile_hint %d with split operands (0 = by shape, 1..5)", cfg);
-    if (cfg == 0) {
-      int64_t t256 = 0;
-      int nmax = 0;
-      bool one_seg = true;
-      for (int j = 0; j < nprob; ++j) {
-        t256 += (int64_t)((g.p[j].M + 255) / 256) * ((g.p[j].N + 255) / 256);
-        nmax = g.p[j].N > nmax ? g.p[j].N : nmax;
-        one_seg = one_seg && g.p[j].nseg == 1;
-      }
-      cfg = (one_seg && nmax >= 2048 && t256 >= 150 && v2a_detail::g_gemm_tuning.use_8phase) ? 5 : 4;
-    }
-    if (cfg == 5) {
-      for (int j = 0; j < nprob; ++j) {
-        V2A_REQUIRE(g.p[j].nseg == 1, "v2a_gemm_grouped: tile_hint 5 (8-phase) with split operands needs one segment per problem");
-        split_as_three_segments(g.p[j]);
-      }
-      return v2a_detail::launch_gemm_8phase_grouped(g, epi, epi == V2A_EPI_GEGLU ? V2A_BF16 : V2A_F32, s);
-    }
-    switch (cfg) {
-      case 1: return dispatch_grouped_s3<64, 64, 2, 2, 3>(g, epi, s);
-      case 2: return dispatch_grouped_s3<128, 64, 2, 2, 3>(g, epi, s);
-      case 3: return dispatch_grouped_s3<128, 128, 2, 4, 2>(g, epi, s);
-      default: return dispatch_grouped_s3<64, 128, 2, 4, 3>(g, epi, s);
-    }
-  }
-  // tile shape: tile_hint k + 1 = configuration k as for v2a_gemm (7 = the 256x256 8-phase kernel); 0 = by the widest output of the group
-  int cfg = args[0].tile_hint - 1;
-  if (cfg < 0) {
-    int64_t t256 = 0;
-    int nmax = 0;
-    for (int j = 0; j < nprob; ++j) {
-      t256 += (int64_t)((g.p[j].M + 255) / 256) * ((g.p[j].N + 255) / 256);
-      nmax = g.p[j].N > nmax ? g.p[j].N : nmax;
-    }
-    // wide outputs with enough 256x256 tiles for a round, and anything that fills the chip several times over: the 8-phase kernel
-    // (v2a_gemm's own thresholds, applied to the group's tile count); launches that cannot fill the chip: 128x128 with eight waves
-    cfg = (v2a_detail::g_gemm_tuning.use_8phase && ((nmax >= 2048 && t256 >= 150) || (nmax > 512 && t256 >= 400))) ? 6 : (t256 >= 400 ? 0 : 12);
-  }
-  switch (cfg) {
-    case 6: return v2a_detail::launch_gemm_8phase_grouped(g, epi, epi == V2A_EPI_GATE_RESID ? V2A_F32 : V2A_BF16, s);
-    case 0: return dispatch_grouped<128, 256, 2, 4>(g, epi, s);
-    case 1: return dispatch_grouped<128, 128, 2, 2>(g, epi, s);
-    case 3: return dispatch_grouped<64, 64, 2, 2>(g, epi, s);
-    case 12: return dispatch_grouped<128, 128, 2, 4, 3>(g, epi, s);
-    case 14: return dispatch_grouped<128, 64, 4, 2, 3>(g, epi, s);
-    case 15: return dispatch_grouped<64, 128, 2, 4, 3>(g, epi, s);
-  }
-  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped: tile_hint %d (supported: 0, 1, 2, 4, 7, 13, 15, 16)", args[0].tile_hint);
 }

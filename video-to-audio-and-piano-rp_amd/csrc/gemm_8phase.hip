@@ -21,7 +21,8 @@
 // SIMDs pairwise), so on every SIMD one wave multiplies while its partner reads LDS and issues DMA.  vmcnt is never 0 inside
 // the loop: three half tiles stay in flight across every barrier.
 //
-// Dense operands only (no offset tables); up to 3 K-concatenated A segments; epilogues shared with gemm.hip.
+// Dense operands only (no offset tables); up to 3 K-concatenated A segments; split (hi | lo plane) operands as three passes over the
+// logical K (GemmParams::s3_kl); epilogues shared with gemm.hip.
 #include "gemm_common.h"
 
 namespace {
@@ -38,14 +39,8 @@ constexpr int kSkip = 0;
 // was 2-3 % faster per launch only while its DMAs were issued in the read blocks, where the wave row that runs one barrier behind may
 // still have fragment reads of the restaged half tile in flight: safe by timing, not by a barrier.  Issued behind the barriers that make
 // it safe by construction it was 10-15 % slower than four phases: profiles/r03_8phase_two_phase_mode.txt.  Four phases stay.)
-// PERSISTENT (round 4): a workgroup walks the virtual block ids b, b + gridDim.x, ... (gridDim.x a multiple of 8, so b & 7 stays the XCD
-// label of the tile order) and PREFETCHES across tiles: when the K loop of a tile ends, K tile 0 of the workgroup's next tile is
-// requested into LDS buffer 0 BEFORE the epilogue (whose staging slabs live in buffer 1, which held the last K tile), so that tile's
-// operand latency and the epilogue's stores overlap instead of adding up -- at K = 1024 prologue + epilogue were ~11 us of a ~27 us
-// tile round (profiles/r03_8phase_skip_probe.txt).  Needs an even number of K tiles (every tile then starts in buffer 0); the host
-// launches one workgroup per tile otherwise, and the loop below runs once.
-template <int EPI, typename OutT, int MODE, bool GROUPED = false>
-__global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const std::conditional_t<GROUPED, v2a_detail::GemmGroup, GemmParams> arg) {
+template <int EPI, typename OutT, int MODE>
+__global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   constexpr bool STAGGER = MODE != 2;
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, TM = 8, TN = 4;
   constexpr int HALF = 128 * 128;               // bytes of a half tile
@@ -59,95 +54,60 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const std::condition
   const int wr = wave >> 2, wc = wave & 3;      // waves w and w + 4 (same wc) share a SIMD
   const int lr = lane & 15, lq = lane >> 4;
 
-  // ---- the walk over virtual block ids: a block id names a (problem, tile) pair; ids in the padding between the problems of a group
-  // (starts are multiples of 8) name nothing and are skipped
-  int total;
-  if constexpr (GROUPED) total = arg.total;
-  else total = arg.tiles_m * arg.tiles_n;
-  const int stride = (int)gridDim.x;
-  // (the problem of a tile is carried as an INDEX and its parameter block is re-derived from the kernel argument at every use: a
-  // loop-carried POINTER into the argument makes the compiler copy the whole by-value argument to scratch and read every field from there)
-  auto prob = [&](int j) -> const GemmParams& {
-    if constexpr (GROUPED) return arg.p[j];
-    else return arg;
-  };
-  auto resolve = [&](int vb, int& j, int& tm, int& tn) -> bool {
-    if (vb >= total) return false;
-    int b = vb;
-    j = 0;
-    if constexpr (GROUPED) {
-      j = (b >= arg.start[1] ? 1 : 0) + (b >= arg.start[2] ? 1 : 0);
-      b -= arg.start[j];
-    }
-    const GemmParams& q = prob(j);
-    if (b >= q.tiles_m * q.tiles_n) return false;
-    tile_of_block(q, b, tm, tn);
-    return true;
-  };
-  auto next_valid = [&](int& vb, int& j, int& tm, int& tn) -> bool {
-    while (vb < total) {
-      if (resolve(vb, j, tm, tn)) return true;
-      vb += stride;
-    }
-    return false;
-  };
-  int vb = blockIdx.x;
-  int pj = 0;
-  int tm = 0, tn = 0;
-  if (!next_valid(vb, pj, tm, tn)) return;
+  int tm, tn;
+  tile_of_block(p, blockIdx.x, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- LDS-DMA source geometry of the CURRENT tile: wave w fills 8-row groups w and w + 8 of every half tile.
-  // Everything derived from the lane id is recomputed per tile from a LAUNDERED copy of it (an empty asm the compiler cannot see
-  // through): kept as loop invariants these ~20 registers stayed live across the epilogue -- whose own peak already sits at the
-  // register file's edge -- and the allocator spilled ~200 values per lane around it.
-  auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
-  int srow;
-  uint32_t schunk_b;               // byte offset of the logical chunk this lane fetches
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- LDS-DMA source geometry: wave w fills 8-row groups w and w + 8 of every half tile
+  const int srow = lane >> 3;
+  const uint32_t schunk_b = (uint32_t)(((lane & 7) ^ srow) << 4);   // byte offset of the logical chunk this lane fetches
   int arow[2][2];            // global A row per (half s, group i)
   uint32_t woff[2][2];       // byte offset into W per (half s, group i)
-  const char* wbase;
-  int nk, nseg;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 8 * (wave + 8 * i) + srow;                 // local row of the half tile
+      const int ar = m0 + r + ((r >= 64) ? 64 : 0) + 64 * s;
+      arow[s][i] = ar < p.M ? ar : p.M - 1;
+      const int wrw = n0 + 64 * (r >> 5) + (r & 31) + 32 * s;
+      woff[s][i] = (uint32_t)(((int64_t)(wrw < p.N ? wrw : p.N - 1) * p.ldw) * 2) + schunk_b;
+    }
+  const char* wbase = reinterpret_cast<const char*>(p.w);
+  const int nk = p.K / 64;
+
   // segment table as scalar base + deltas: inside the K loop a segment switch is two s_cselect per quantity, not a
   // kernel-argument load (whose s_waitcnt lgkmcnt(0) would also wait for the phase's fragment reads before the DMA could
   // issue).  Deltas rather than a select between the three values themselves: a select of two captured variables becomes
   // a load through a selected address, which keeps the whole closure on the stack (176 B of scratch per lane, measured).
-  int64_t a0, da1, da2, w_adj2;
-  int32_t ldb0, dl1, dl2;
-  int kend0, kend1, dk2;
-  auto setup_tile = [&](const GemmParams& p, int tm_, int tn_) {
-    const int m0 = tm_ * BM, n0 = tn_ * BN;
-    const int ln = launder(lane);
-    srow = ln >> 3;
-    schunk_b = (uint32_t)(((ln & 7) ^ srow) << 4);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = 8 * (wave + 8 * i) + srow;                 // local row of the half tile
-        const int ar = m0 + r + ((r >= 64) ? 64 : 0) + 64 * s;
-        arow[s][i] = ar < p.M ? ar : p.M - 1;
-        const int wrw = n0 + 64 * (r >> 5) + (r & 31) + 32 * s;
-        woff[s][i] = (uint32_t)(((int64_t)(wrw < p.N ? wrw : p.N - 1) * p.ldw) * 2) + schunk_b;
-      }
-    wbase = reinterpret_cast<const char*>(p.w);
-    nk = p.K / 64;
-    nseg = p.nseg;
-    a0 = (int64_t)p.a[0];
-    da1 = nseg > 1 ? (int64_t)p.a[1] - a0 : 0;
-    da2 = nseg > 2 ? (int64_t)p.a[2] - (int64_t)p.a[1] : 0;
-    ldb0 = (int32_t)(p.lda[0] * 2);
-    dl1 = nseg > 1 ? (int32_t)(p.lda[1] * 2) - ldb0 : 0;
-    dl2 = nseg > 2 ? (int32_t)((p.lda[2] - p.lda[1]) * 2) : 0;
-    kend0 = nseg > 1 ? p.kend[0] : 0x7fffffff;
-    kend1 = nseg > 2 ? p.kend[1] : 0x7fffffff;
-    dk2 = nseg > 2 ? p.kend[1] - p.kend[0] : 0;
-    w_adj2 = p.w_adj2;
-  };
+  const int nseg = p.nseg;
+  const int64_t a0 = (int64_t)p.a[0];
+  const int64_t da1 = nseg > 1 ? (int64_t)p.a[1] - a0 : 0, da2 = nseg > 2 ? (int64_t)p.a[2] - (int64_t)p.a[1] : 0;
+  const int32_t ldb0 = (int32_t)(p.lda[0] * 2);
+  const int32_t dl1 = nseg > 1 ? (int32_t)(p.lda[1] * 2) - ldb0 : 0, dl2 = nseg > 2 ? (int32_t)((p.lda[2] - p.lda[1]) * 2) : 0;
+  const int kend0 = nseg > 1 ? p.kend[0] : 0x7fffffff, kend1 = nseg > 2 ? p.kend[1] : 0x7fffffff;
+  const int dk2 = nseg > 2 ? p.kend[1] - p.kend[0] : 0;
+  // split operands (GemmParams::s3_kl): K tile kt belongs to pass kt / nkl and is K tile kt % nkl of the logical K; pass 2 reads the lo
+  // plane of its A segment (the segment's K extent further along the row), pass 1 the lo plane of W (s3_kl elements further along the row)
+  const int kl = p.s3_kl;
+  const int nkl = kl > 0 ? kl / 64 : 0x3fffffff;                 // plain operands: every K tile is in "pass 0"
+  const int sb0 = kl > 0 ? 2 * (nseg > 1 ? p.kend[0] : kl) : 0;  // bytes from a row's hi plane to its lo plane, by segment
+  const int dsb1 = kl > 0 && nseg > 1 ? 2 * ((nseg > 2 ? p.kend[1] : kl) - p.kend[0]) - sb0 : 0;
+  const int dsb2 = kl > 0 && nseg > 2 ? 2 * (kl - p.kend[1]) - (sb0 + dsb1) : 0;
+  const int64_t wlo = (int64_t)kl * 2;
   auto stage_a = [&](int s, int kt, int buf) {
-    const int k0 = kt * 64;
+    const bool p1 = kt >= nkl, p2 = kt >= 2 * nkl;         // p2 implies p1
+    const int k0 = (kt - (p1 ? nkl : 0) - (p2 ? nkl : 0)) * 64;
     const bool s1 = k0 >= kend0, s2 = k0 >= kend1;       // s2 implies s1
     const int kbeg = (s1 ? kend0 : 0) + (s2 ? dk2 : 0);
-    const char* ab = reinterpret_cast<const char*>(a0 + (s1 ? da1 : 0) + (s2 ? da2 : 0)) + (int64_t)(k0 - kbeg) * 2;
+    const int lo = p2 ? sb0 + (s1 ? dsb1 : 0) + (s2 ? dsb2 : 0) : 0;
+    const char* ab = reinterpret_cast<const char*>(a0 + (s1 ? da1 : 0) + (s2 ? da2 : 0)) + (int64_t)(k0 - kbeg) * 2 + lo;
     const uint32_t ldb = (uint32_t)(ldb0 + (s1 ? dl1 : 0) + (s2 ? dl2 : 0));
     char* dst = smem_raw + buf * BUF + s * HALF;
 #pragma unroll
@@ -158,7 +118,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const std::condition
     }
   };
   auto stage_b = [&](int s, int kt, int buf) {
-    const char* wb = wbase + (int64_t)kt * 128 + (kt * 64 >= kend1 ? w_adj2 : 0);
+    const bool p1 = kt >= nkl, p2 = kt >= 2 * nkl;
+    const char* wb = wbase + (int64_t)(kt - (p1 ? nkl : 0) - (p2 ? nkl : 0)) * 128 + (p1 && !p2 ? wlo : 0);
     char* dst = smem_raw + buf * BUF + (2 + s) * HALF;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -166,17 +127,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const std::condition
                                        (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
   };
 
-  f32x4 acc[TM][TN];
   // ---- fragment reads: row = sub-tile base + 16*i + lr, chunk = (4*kk + lq) ^ (row & 7) = ... ^ (lr & 7)
-  int a_frag_off, b_frag_off, ch0, ch1;
-  auto setup_frags = [&]() {
-    const int ln = launder(lane);
-    const int lr_ = ln & 15, lq_ = ln >> 4;
-    a_frag_off = (64 * wr + lr_) * 128;
-    b_frag_off = (32 * wc + lr_) * 128;
-    ch0 = ((0 + lq_) ^ (lr_ & 7)) << 4;
-    ch1 = ((4 + lq_) ^ (lr_ & 7)) << 4;
-  };
+  const int a_frag_off = (64 * wr + lr) * 128;
+  const int b_frag_off = (32 * wc + lr) * 128;
+  const int ch0 = ((0 + lq) ^ (lr & 7)) << 4, ch1 = ((4 + lq) ^ (lr & 7)) << 4;
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];
   auto read_a = [&](int s, int buf) {
     const char* base = smem_raw + buf * BUF + s * HALF + a_frag_off;
@@ -209,8 +163,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const std::condition
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-  // folded RMSNorm (consumer): the tile rows' partial sums are requested ahead of the operand DMAs (gemm_common.h, rowscale_load)
+  // folded RMSNorm (consumer): request the tile rows' partial sums ahead of the operand DMAs (gemm_common.h, rowscale_load)
   float* rs_lds = reinterpret_cast<float*>(smem_raw + 2 * BUF);
+  const bool scaled = p.rssq != nullptr && p.vec_epi;
+  RowScaleLoad rsl;
+  if (scaled && tid < 256) rowscale_load(p, m0 + tid, rsl);
+  // ---- prologue: K tile 0 whole, plus the three halves of K tile 1 the steady state would have issued already
+  stage_a(0, 0, 0);
+  stage_b(0, 0, 0);
+  stage_b(1, 0, 0);
+  stage_a(1, 0, 0);
+  if (nk > 1) {
+    stage_a(0, 1, 1);
+    stage_b(0, 1, 1);
+    stage_b(1, 1, 1);
+    if (scaled && tid < 256) rs_lds[tid] = rowscale_finish(p, rsl);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    if (scaled && tid < 256) rs_lds[tid] = rowscale_finish(p, rsl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if constexpr (STAGGER) {
+    if (wr == 1) __builtin_amdgcn_s_barrier();     // wave row 1 runs one barrier behind wave row 0 from here on
+  }
 
   auto ktile = [&](auto buf_c, int t) {
     constexpr int B = decltype(buf_c)::value;
@@ -254,83 +230,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const std::condition
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
-
-  // ---- prologue of the first tile: K tile 0 whole, plus the three halves of K tile 1 the steady state would have issued already
-  setup_tile(prob(pj), tm, tn);
-  stage_a(0, 0, 0);
-  stage_b(0, 0, 0);
-  stage_b(1, 0, 0);
-  stage_a(1, 0, 0);
-  for (;;) {
-    const GemmParams& p = prob(pj);               // the tile whose K loop runs now
-    const int m0 = tm * BM, n0 = tn * BN;
-    setup_tile(p, tm, tn);                        // (again: the copy used for the K tile 0 request died before the epilogue)
-    setup_frags();
-    // folded RMSNorm (consumer): the partial sums of the tile's rows, requested ahead of K tile 1's DMAs and added up behind them
-    const bool scaled = p.rssq != nullptr && p.vec_epi;
-    RowScaleLoad rsl;
-    if (scaled && tid < 256) rowscale_load(p, m0 + tid, rsl);
-    // K tile 0 is in flight (requested by the prologue above, or before the previous tile's epilogue); buffer 1 is free again
-    if (nk > 1) {
-      stage_a(0, 1, 1);
-      stage_b(0, 1, 1);
-      stage_b(1, 1, 1);
-      if (scaled && tid < 256) rs_lds[tid] = rowscale_finish(p, rsl);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      if (scaled && tid < 256) rs_lds[tid] = rowscale_finish(p, rsl);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_s_barrier();
-    if constexpr (STAGGER) {
-      if (wr == 1) __builtin_amdgcn_s_barrier();     // wave row 1 runs one barrier behind wave row 0 from here on
-    }
-    for (int t = 0; t < nk; t += 2) {
-      ktile(I0{}, t);
-      if (t + 1 < nk) ktile(I1{}, t + 1);
-    }
-    if constexpr (STAGGER) {
-      if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two wave rows: everyone is out of the K loop after this
-    }
-    // every DMA was retired by the last P4 wait; the last barrier above orders all fragment reads before what follows.
-    // Next tile of this workgroup: its K tile 0 goes to buffer 0 NOW (an even K-tile count left the last K tile in buffer 1, where
-    // the epilogue's staging slabs go), its geometry replaces the finished tile's in the same registers.
-    int vbn = vb + stride, tmn = 0, tnn = 0, pjn = 0;
-    const bool has_next = next_valid(vbn, pjn, tmn, tnn);
-    if (has_next) {
-      setup_tile(prob(pjn), tmn, tnn);
-      stage_a(0, 0, 0);
-      stage_b(0, 0, 0);
-      stage_b(1, 0, 0);
-      stage_a(1, 0, 0);
-    }
-    constexpr int EBUF = 1;                        // (with one K tile -- the only odd count that reaches here -- there is no next tile)
-    if (p.vec_epi) {
-      static_assert(8 * 16 * (WN + 4) * 4 <= BUF, "epilogue slabs must fit in one LDS buffer");
-      float* tile = reinterpret_cast<float*>(smem_raw + (has_next ? EBUF * BUF : 0)) + wave * (16 * (WN + 4));
-      EpiPrefetch<EPI, TM, WN, false> pf;
-      gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN, false>(p, acc, tile, m0 + wr * WM, n0 + wc * WN, lane, pf, scaled ? rs_lds + wr * WM : nullptr);
-    } else {
-      gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wr, wc, lr, lq);
-    }
-    if (!has_next) break;
-    vb = vbn; pj = pjn; tm = tmn; tn = tnn;
-    // every wave is done with the staging slabs and the row scales of the finished tile before buffer 1 / rs_lds are written again
-    __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nk; t += 2) {
+    ktile(I0{}, t);
+    if (t + 1 < nk) ktile(I1{}, t + 1);
   }
-}
-
-// Grid of a launch with `total` virtual block ids: one workgroup per id, or -- when every problem has an even number of K tiles (the
-// cross-tile prefetch starts every tile in LDS buffer 0) and there is more than one round of work -- one persistent workgroup per CU.
-// 256 = the CUs of the MI355X; a multiple of 8 keeps (block id & 7) the XCD label of the tile order.
-static int persistent_grid(int total, bool even_k) {
-  const int per_id = (total + 7) / 8 * 8;
-  if (!even_k || !v2a_detail::g_8ph_persistent) return per_id;
-  return per_id < 256 ? per_id : 256;
+  if constexpr (STAGGER) {
+    if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two wave rows: everyone is out of the K loop after this
+  }
+  // every DMA was retired by the last P4 wait; the last barrier above orders all fragment reads before the slab writes
+  if (p.vec_epi) {
+    static_assert(8 * 16 * (WN + 4) * 4 <= 2 * BUF, "epilogue slabs must fit in the ring memory");
+    float* tile = reinterpret_cast<float*>(smem_raw) + wave * (16 * (WN + 4));
+    EpiPrefetch<EPI, TM, WN, false> pf;
+    gemm_epilogue_lds<EPI, OutT, TM, TN, WM, WN, false>(p, acc, tile, m0 + wr * WM, n0 + wc * WN, lane, pf, scaled ? rs_lds + wr * WM : nullptr);
+  } else {
+    gemm_epilogue<EPI, OutT, TM, TN, WM, WN>(p, acc, m0, n0, wr, wc, lr, lq);
+  }
 }
 
 template <int EPI, typename OutT>
@@ -338,7 +253,7 @@ int launch_8ph(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
   v2a_detail::fill_tile_map(p, 256, 256);
   constexpr size_t smem = 2 * 4 * 128 * 128 + 256 * 4;     // two buffers of four half tiles + one row scale per tile row (folded RMSNorm)
-  const int tiles = persistent_grid(((p.M + 255) / 256) * ((p.N + 255) / 256), (p.K / 64) % 2 == 0);
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   const int mode = v2a_detail::g_gemm_tuning.use_8phase;
   auto go = [&](auto kern) -> int {
     static std::atomic<uint64_t> lds_set{0};
@@ -353,41 +268,7 @@ int launch_8ph(const GemmParams& p_in, hipStream_t s) {
   return v2a_check_launch("v2a_gemm(8-phase)");
 }
 
-template <int EPI, typename OutT>
-int launch_8ph_grouped(v2a_detail::GemmGroup& g, hipStream_t s) {
-  int total = 0;
-  bool even_k = true;
-  for (int j = 0; j < g.nprob; ++j) {
-    v2a_detail::fill_tile_map(g.p[j], 256, 256);
-    g.start[j] = total;
-    total += (g.p[j].tiles_m * g.p[j].tiles_n + 7) / 8 * 8;
-    even_k = even_k && (g.p[j].K / 64) % 2 == 0;
-  }
-  for (int j = g.nprob; j <= v2a_detail::kGroupMax; ++j) g.start[j] = 0x7fffffff;
-  g.total = total;
-  constexpr size_t smem = 2 * 4 * 128 * 128 + 256 * 4;
-  auto kern = gemm_bf16_8ph_kernel<EPI, OutT, 1, true>;
-  static std::atomic<uint64_t> lds_set{0};
-  if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm_grouped(8-phase)")) return rc;
-  hipLaunchKernelGGL(kern, dim3(persistent_grid(total, even_k)), dim3(512), smem, s, g);
-  return v2a_check_launch("v2a_gemm_grouped(8-phase)");
-}
-
 }  // namespace
-
-int v2a_detail::launch_gemm_8phase_grouped(GemmGroup& g, int epilogue, int out_dtype, hipStream_t s) {
-  switch (epilogue) {
-    case V2A_EPI_STORE:
-      return out_dtype == V2A_BF16 ? launch_8ph_grouped<V2A_EPI_STORE, bf16_t>(g, s) : launch_8ph_grouped<V2A_EPI_STORE, float>(g, s);
-    case V2A_EPI_GEGLU:
-      if (out_dtype == V2A_BF16) return launch_8ph_grouped<V2A_EPI_GEGLU, bf16_t>(g, s);
-      break;
-    case V2A_EPI_GATE_RESID:
-      if (out_dtype == V2A_F32) return launch_8ph_grouped<V2A_EPI_GATE_RESID, float>(g, s);
-      break;
-  }
-  return v2a_fail(V2A_ERR_ARG, "v2a_gemm_grouped(8-phase): unsupported epilogue %d / out_dtype %d", epilogue, out_dtype);
-}
 
 int v2a_detail::launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStream_t s) {
   const bool out_f32 = out_dtype == V2A_F32;

@@ -48,11 +48,7 @@ struct GemmParams {
   int64_t rssq_ld;
   int32_t rssq_parts;
   float rnorm;
-  int32_t xcd_gm, xcd_gn;   // the XCDs of the launch as a gm x gn grid over the tile space (gm * gn == 8, or == the XCDs of xcd_mask): see tile_of_block
-  // XCD-subset placement (v2a_gemm_args.xcd_mask / tile_counters): workgroups that find themselves on an XCD of the mask claim the
-  // tiles of that XCD's chunk through a device counter, the others leave at once
-  int32_t* tile_ctr;
-  int32_t xcd_mask, xcd_cnt;
+  int32_t xcd_gm, xcd_gn;   // the 8 XCDs of the launch as a gm x gn grid over the tile space (gm * gn == 8): see tile_of_block
   // the rectangles of the tile order, filled on the host once the tile shape is known (fill_tile_map): first tile, height and
   // tile count of each, and 1 / height so that the workgroup's tile costs one multiply and a correction instead of ~40 integer
   // divisions at the head of every kernel
@@ -61,25 +57,11 @@ struct GemmParams {
   // split (hi | lo plane) outputs of the bf16x3 mode: out2 = the shadow (lo plane N columns after hi), out = the GEGLU hidden
   // (lo plane N / 2 columns after hi)
   int32_t out2_split, out_split;
-  // 8-phase kernel: byte adjustment of the W tile base for K tiles of the THIRD segment.  Split operands on that kernel run as
-  // three K segments [A_hi | A_hi | A_lo] against the weight row [W_hi | W_lo]: segments 0 and 1 walk the row as it lies, segment 2
-  // needs W_hi again (-2 * K_logical elements)
-  int64_t w_adj2;
+  // 8-phase kernel, split (hi | lo plane) operands: s3_kl = the LOGICAL K (sum of the segments' extents), K = 3 * s3_kl, and the K loop
+  // walks the logical K three times: pass 0 = A_hi x W_hi, pass 1 = A_hi x W_lo, pass 2 = A_lo x W_hi -- every pass over all (up to
+  // three) logical segments, whose rows are [hi k | lo k] (lda >= 2k), against weight rows [W_hi (s3_kl) | W_lo (s3_kl)].  0 = plain operands
+  int32_t s3_kl;
   int32_t dbg;              // probe builds only (-DV2A_GEMM_PROBE, scripts/probes/kloop_probe.py): K-loop parts switched off by bit
-};
-
-// Grouped launch (v2a_gemm_grouped): up to three independent problems behind ONE kernel launch -- the same op of the audio, text and
-// frames blocks of a layer, whose workgroups then fill the chip together instead of queueing on three streams.  Workgroup bid belongs
-// to problem j = the last one with start[j] <= bid and computes tile bid - start[j] of it (starts are multiples of 8 so that
-// bid & 7, the XCD label of the tile order, is the physical one; a workgroup past the problem's tile count leaves at once).
-// The host orders the problems by K, longest first: the dispatcher hands workgroups out in index order, so when the group does not
-// fit the chip in one round the short tiles are the ones that wait.
-constexpr int kGroupMax = 3;
-struct GemmGroup {
-  int32_t nprob;
-  int32_t total;                  // block ids of the launch (padded tile counts summed): persistent workgroups walk [0, total)
-  int32_t start[kGroupMax + 1];
-  GemmParams p[kGroupMax];
 };
 
 // tile-shape selectors of the LDS-DMA bf16 kernels (v2a_set_tuning)
@@ -96,11 +78,9 @@ extern int g_attn_one_group_from;    // v2a_attention: workgroup count from whic
 extern int g_dwconv_rows_per_wave;   // 4 or 8 (v2a_set_tuning)
 extern int g_probe_dbg;              // v2a_tuning.reserved[0] (probe builds)
 extern int g_dwconv_stream;          // 0: never use the streaming depthwise conv (v2a_tuning.dwconv_rows_per_wave = -1)
-extern int g_8ph_persistent;         // 8-phase kernel: persistent workgroups with cross-tile prefetch (0: one workgroup per tile, A/B)
 
 // 256x256 8-phase kernel (gemm_8phase.hip)
 int launch_gemm_8phase(const GemmParams& p, int epilogue, int out_dtype, hipStream_t stream);
-int launch_gemm_8phase_grouped(GemmGroup& g, int epilogue, int out_dtype, hipStream_t stream);
 
 // host: the gm x gn rectangles of the tile space for a BM x BN tile shape (xcd_gm / xcd_gn chosen by v2a_gemm)
 inline void fill_tile_map(GemmParams& p, int BM, int BN) {
@@ -160,16 +140,6 @@ __device__ __forceinline__ void tile_of_block(const GemmParams& p, int bid, int&
   const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);      // bijective: position in the linear order
   tile_of_index(p, L, tm, tn);
 }
-
-// grouped launch: the problem of workgroup `bid` and its index inside that problem (all wave-uniform: scalar compares and selects)
-__device__ __forceinline__ const GemmParams& group_pick(const v2a_detail::GemmGroup& g, int& bid) {
-  const int j = (bid >= g.start[1] ? 1 : 0) + (bid >= g.start[2] ? 1 : 0);
-  bid -= g.start[j];
-  return g.p[j];
-}
-
-// XCD-subset placement: the physical XCD of this workgroup (HW_REG_XCC_ID, bits 3:0)
-__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20) & 7); }
 
 template <typename T> struct TileCfg;
 template <> struct TileCfg<bf16_t> {
@@ -357,8 +327,7 @@ template <int EPI, int TM, int WN, bool ON> struct EpiPrefetch {
           if (m < M && full) {
             int64_t off = (int64_t)m * ldr;
             if constexpr (SCAT) { if (orow) off = ro[i][q]; }
-            // a grouped launch runs problems with and without a residual / gate through one instantiation: absent operands read as
-            // 0 / 1 (resid + 1 * acc is exactly the RESID epilogue, 0 + 1 * acc the plain store)
+            // absent operands read as 0 / 1 (resid + 1 * acc is exactly the RESID epilogue, 0 + 1 * acc the plain store)
             rs[i][q] = has_res ? *reinterpret_cast<const f32x4*>(resid + off) : f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (GATE) gt[i][q] = has_gate ? *reinterpret_cast<const f32x4*>(step_vec(p.gate, p.step, p.gss, p.gbs, p.gbs ? m / p.rpb : 0) + n) : f32x4{1.f, 1.f, 1.f, 1.f};
           }

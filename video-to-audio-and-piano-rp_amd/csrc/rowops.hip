@@ -9,7 +9,7 @@ namespace v2a_detail { extern int g_dwconv_rows_per_wave; extern int g_dwconv_st
 
 thread_local char v2a_err_buf[512] = {0};
 
-extern "C" int v2a_abi_version(void) { return 7; }
+extern "C" int v2a_abi_version(void) { return 8; }
 extern "C" const char* v2a_last_error(void) { return v2a_err_buf; }
 
 namespace {
@@ -249,36 +249,6 @@ __global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_kernel(const floa
   const int xcd = flat & 7, slot = flat >> 3;
   const int cblk = slot % CB, walker = slot / CB;        // walkers per XCD label = `walkers`
   dwconv_body<KS, TN, NORM>(x, out, wt, bias, B, N, d, len, P, walkers, nrm, xcd, cblk, walker);
-}
-
-// Grouped launch (v2a_dwconv_grouped): the convolutions of the audio, text and frames blocks of a layer in one launch.  The 256-channel
-// blocks of all problems form the x dimension of the grid (4 + 5 + 2 at the shipped widths); a workgroup takes the problem its channel
-// block belongs to.  B, N, the length array and the item walk are shared.
-constexpr int kDwGroupMax = 3;
-struct DwProb {
-  const float* x;
-  float* out;
-  const float* wt;
-  const float* bias;
-  int32_t d, pad;
-  v2a_dwconv_norm nrm;
-};
-struct DwGroup {
-  int32_t nprob;
-  int32_t cbstart[kDwGroupMax + 1];
-  DwProb p[kDwGroupMax];
-};
-template <int KS, int TN, bool NORM>
-__global__ __launch_bounds__(256, TN == 4 ? 3 : 2) void dwconv_group_kernel(const DwGroup g, int B, int N, const int32_t* len, int P, int walkers) {
-  const int CB = gridDim.x;
-  const int flat = blockIdx.y * CB + blockIdx.x;
-  const int xcd = flat & 7, slot = flat >> 3;
-  int cblk = slot % CB;
-  const int walker = slot / CB;
-  const int j = (cblk >= g.cbstart[1] ? 1 : 0) + (cblk >= g.cbstart[2] ? 1 : 0);
-  cblk -= g.cbstart[j];
-  const DwProb& q = g.p[j];
-  dwconv_body<KS, TN, NORM>(q.x, q.out, q.wt, q.bias, B, N, q.d, len, P, walkers, q.nrm, xcd, cblk, walker);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -839,62 +809,6 @@ static int dwconv_launch(const float* x, float* out, const float* wt, const floa
     hipLaunchKernelGGL((dwconv_kernel<31, 4, false>), grid, block, 0, s, x, out, wt, bias, B, N, d, len, P, walkers, none);
   }
   return v2a_check_launch("v2a_dwconv_silu_residual");
-}
-
-// Up to three convolutions (same B, N, kernel size and length array; own tensors, widths and folded norms) in one launch while a launch
-// cannot fill the chip; from there on (the streaming kernel's regime) they run one after another through the single-problem path.
-extern "C" int v2a_dwconv_grouped(const v2a_dwconv_args* args, int32_t nprob, int32_t B, int32_t N, int32_t ksize, const int32_t* len,
-                                  v2a_stream_t stream) {
-  V2A_REQUIRE(args != nullptr && nprob >= 1 && nprob <= kDwGroupMax, "v2a_dwconv_grouped: %d problems (1..%d)", nprob, kDwGroupMax);
-  const bool with_norm = args[0].norm.out_bf16 != nullptr;
-  int cb_total = 0;
-  bool big = nprob == 1;
-  for (int j = 0; j < nprob; ++j) {
-    V2A_REQUIRE((args[j].norm.out_bf16 != nullptr) == with_norm, "v2a_dwconv_grouped: all problems with or all without the folded norm");
-    V2A_REQUIRE(args[j].d > 0 && args[j].d % 4 == 0, "v2a_dwconv_grouped: problem %d: d=%d", j, args[j].d);
-    const int cb = (args[j].d / 4 + 63) / 64;
-    cb_total += cb;
-    if ((int64_t)B * cb * ((N + 95) / 96) >= 192) big = true;      // dwconv_launch would consider the streaming kernel
-  }
-  if (big) {
-    for (int j = 0; j < nprob; ++j)
-      if (int rc = dwconv_launch(args[j].x, args[j].out, args[j].wt, args[j].bias, B, N, args[j].d, ksize, len, with_norm ? &args[j].norm : nullptr, stream)) return rc;
-    return V2A_OK;
-  }
-  V2A_REQUIRE(ksize == 31 && B > 0 && N > 0, "v2a_dwconv_grouped: kernel_size %d (only 31 is built), B=%d N=%d", ksize, B, N);
-  DwGroup g{};
-  g.nprob = nprob;
-  int cbs = 0;
-  for (int j = 0; j < nprob; ++j) {
-    const v2a_dwconv_args& a = args[j];
-    V2A_REQUIRE(a.x && a.out && a.wt && a.bias && a.x != a.out, "v2a_dwconv_grouped: problem %d: null pointer or out aliases x", j);
-    if (with_norm) {
-      const v2a_dwconv_norm* norm = &a.norm;
-      const int d = a.d;
-      V2A_REQUIRE(norm->out_bf16 && norm->norm_gamma && norm->norm_ssq && d % 32 == 0 && norm->ld_out_bf16 % 4 == 0 && norm->ld_out_bf16 >= d &&
-                      ((uintptr_t)norm->out_bf16 & 7) == 0 && ((uintptr_t)norm->norm_gamma & 15) == 0 && norm->norm_step_stride % 4 == 0 &&
-                      norm->norm_batch_stride % 4 == 0 && norm->ld_norm_ssq >= d / 32 && (!norm->split || norm->ld_out_bf16 >= 2 * (int64_t)d),
-                  "v2a_dwconv_grouped: problem %d: the folded norm needs out_bf16, norm_gamma, norm_ssq, d %% 32 == 0 (d=%d) and aligned rows", j, d);
-    }
-    g.p[j].x = a.x; g.p[j].out = a.out; g.p[j].wt = a.wt; g.p[j].bias = a.bias; g.p[j].d = a.d;
-    g.p[j].nrm = a.norm;
-    g.cbstart[j] = cbs;
-    cbs += (a.d / 4 + 63) / 64;
-  }
-  for (int j = nprob; j <= kDwGroupMax; ++j) g.cbstart[j] = 0x7fffffff;
-  constexpr int TN = 4;
-  const int P = (N + 4 * TN - 1) / (4 * TN);
-  const int items = P * B, ipx = (items + 7) / 8;
-  const int cap = max(1, 3 * 256 / 8 / cb_total);
-  const int rounds = (ipx + cap - 1) / cap;
-  const int walkers = (ipx + rounds - 1) / rounds;
-  V2A_REQUIRE(walkers >= 1 && (int64_t)walkers * 8 <= 65535 && (int64_t)walkers * rounds * 8 >= items,
-              "v2a_dwconv_grouped: grid does not cover the work (items=%d walkers=%d rounds=%d)", items, walkers, rounds);
-  dim3 grid(cb_total, walkers * 8), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (with_norm) hipLaunchKernelGGL((dwconv_group_kernel<31, 4, true>), grid, block, 0, s, g, B, N, len, P, walkers);
-  else hipLaunchKernelGGL((dwconv_group_kernel<31, 4, false>), grid, block, 0, s, g, B, N, len, P, walkers);
-  return v2a_check_launch("v2a_dwconv_grouped");
 }
 
 extern "C" int v2a_dwconv_silu_residual(const float* x, float* out, const float* wt, const float* bias, int32_t B,

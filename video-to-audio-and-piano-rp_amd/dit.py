@@ -296,28 +296,6 @@ class DiTEngine:
         # bf16 and bf16x3 modes, up to three clips (bf16 stand-alone: 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
         # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
         self.fuse_xattn = True
-        # Round 4: chains of GROUPED launches (forward_grouped; bf16 and bf16x3 modes while every RMSNorm is folded, i.e. up to two clips).
-        # The audio block of layer i and the text / frames blocks of layer i+1 are independent and run the same op sequence (x3:1081-1137),
-        # so one op of several streams can be ONE launch (v2a_gemm_grouped / v2a_attention_grouped / v2a_dwconv_grouped).  `chains` cuts the
-        # three streams into chains, each on its own HIP stream: one chain (9 launches per layer, no hand-offs), audio | text + frames,
-        # audio + frames | text, or three chains of single launches (= the schedule of forward()).
-        # Measured (profiles/r04_chains_ab.txt, one clip, mel-frames/s): one chain 5282, a | t+f 5400, a+f | t 5630-5730, three chains 5790-5890
-        # = forward()'s three streams 5720-5870; 8 clips per GPU: one chain 8371 against 8833.  A grouped launch takes 0.75x the sum of its
-        # members' single launches (profiles/r04_group_probe.txt), but lock-step launches lose what three independent queues give for free:
-        # every kernel's tail round is filled by the other queues' workgroups, and latency-bound kernels (attention, convolutions) run beside
-        # bandwidth-bound ones.  Default: three chains of single launches.
-        self.grouped = True
-        self.fold_all_regimes = False       # experiment: RMSNorms folded into GEMM epilogues (and thus grouped chains) at every batch size
-        self.chains = (("a",), ("t",), ("f",))
-        # tile_hint of each grouped launch (cfg + 1 of v2a_gemm's tile configurations; 7 = the 256x256 8-phase kernel, 13 = 128x128 with
-        # eight waves); keys: op for every chain, or ("a+f", op) for the launches of one chain; stand-alone times of every group and tile shape:
-        # scripts/group_probe.py, profiles/r04_group_probe.txt (64x128 / 8 waves = 16 is the best narrow tile for two-problem groups)
-        self.group_tiles = {"cross": 13, "qkv": 16, "out": 16, "ff1": 7, "ff2": 13,
-                            ("a+f", "cross"): 15, ("a+f", "qkv"): 16, ("a+f", "out"): 16, ("a+f", "ff1"): 16, ("a+f", "ff2"): 15,
-                            ("t+f", "cross"): 16, ("t+f", "qkv"): 16, ("t+f", "out"): 16, ("t+f", "ff1"): 1, ("t+f", "ff2"): 16}
-        # ... of the bf16x3 mode's groups (split operands have their own tile numbering, v2a_gemm_grouped: 1 = 64x64, 2 = 128x64,
-        # 3 = 128x128 / 8 waves, 4 = 64x128 / 8 waves, 5 = the 8-phase kernel on three K segments; 0 = by shape)
-        self.group_tiles_split = {"cross": 0, "qkv": 0, "out": 0, "ff1": 5, "ff2": 0}
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
@@ -440,7 +418,7 @@ class DiTEngine:
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
                 tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
-                self.grouped, self.fold_all_regimes, tuple(self.chains), tuple(sorted(self.group_tiles.items(), key=str)), tuple(sorted(self.group_tiles_split.items(), key=str)), self.interleave_capture, self.rope_cross, self.zero_masked_queries)
+                self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
     def _sh(self, buf):
@@ -464,23 +442,6 @@ class DiTEngine:
         if kw.get("out_bf16") is not None:
             kw["out_bf16_split"] = True
         return L.gemm(segs, W, out, compute=L.BF16, a_split=True, **kw)
-
-    def _mm_args(self, segs, W, out, **kw):
-        """The v2a_gemm argument block of one problem of a grouped launch: what _mm would launch on its own."""
-        if kw.get("out_bf16") is not None and "ld_out_bf16" not in kw:
-            kw["ld_out_bf16"] = kw["out_bf16"].stride(-2)
-        if not self.split:
-            return L.gemm_args(segs, W, out, compute=self.cdc, **kw)
-        segs = [(buf, buf.stride(-2), k) for buf, _, k in segs]
-        if kw.get("out_bf16") is not None:
-            kw["out_bf16_split"] = True
-        return L.gemm_args(segs, W, out, compute=L.BF16, a_split=True, **kw)
-
-    def _use_grouped(self):
-        """Grouped single-chain schedule: bf16 operands, every RMSNorm folded into its neighbours (so a block is conv, QKV, attention,
-        out, feed-forward in / out and nothing else), fused RoPE, and launches that cannot fill the chip on their own (<= 2 clips)."""
-        return (self.grouped and self.dev.type == "cuda" and self.cd == torch.bfloat16 and self._fold_gemm()
-                and self._fuse_rope and self.adc in (L.BF16, L.BF16_SPLIT))
 
     def _norm_plain(self, x, hn, rows, d, g):
         L.rmsnorm(x, hn, rows=rows, d=d, gamma=g, split=self.split)
@@ -519,7 +480,7 @@ class DiTEngine:
         """... into a GEMM epilogue only up to two clips: the extra bf16 row pieces cost an out-projection launch 2 us of 24 at
         one clip (a norm launch: 7.7 us) but 20-26 us of 58 at 8 clips per GPU, more than the 16.5 us norm launch they replace
         (the conv fold wins at every size: 46 us against 49 + 16.5)."""
-        return self._fold() and (self._regime() < 2 or self.fold_all_regimes)
+        return self._fold() and self._regime() < 2
 
     def _nprod_ada(self, layer, slot, switch_row=0):
         """Producer side of a folded AdaptiveRMSNorm (audio stream): kwargs for the RESID / GATE_RESID GEMM or the conv that
@@ -810,8 +771,6 @@ class DiTEngine:
         layer), x of the layer ready (eA -> the side streams' own cross-condition GEMMs) and main's cross-condition GEMM
         done (eX -> the side blocks may overwrite the text / frames buffers it read).  All are forward edges: the main
         stream (the critical path) waits only for eT / eF, which the side streams reach with slack."""
-        if self._use_grouped():
-            return self.forward_grouped(n_ctx_seqs)
         p, c, W = self.plan, self.cfg, self.W
         B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
         D, Dt, Df = c.dim, c.dim_text, c.dim_frames
@@ -979,208 +938,6 @@ class DiTEngine:
         else:
             L.rmsnorm(xc, p["hn_a"], rows=rows, d=D, gamma=W.final_g, split=self.split)
             self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels)
-        return p["pred"]
-
-    def forward_grouped(self, n_ctx_seqs: int | None = None):
-        """Transformer.forward as chains of grouped launches (bf16 and bf16x3 modes, up to two clips; see `grouped` / `chains` in __init__).
-
-        The audio block A_i and the text / frames blocks T_i+1, F_i+1 of a layer are independent and run the same op sequence
-        (x3:1081-1137).  `self.chains` partitions the three streams into chains; a chain runs on its own HIP stream and every op of it is
-        ONE launch over the streams it holds (v2a_gemm_grouped / v2a_attention_grouped / v2a_dwconv_grouped):
-          (("a", "t", "f"),)          one chain: 9 launches per layer, no hand-offs, every launch has the chip to itself;
-          (("a",), ("t", "f"))        the audio block beside ONE side chain of two-problem launches;
-          (("a", "f"), ("t",))        the two chains balanced by work (text is the widest stream);
-          (("a",), ("t",), ("f",))    the three-stream schedule of single launches.
-        The chain that holds "a" is the main one (the capture stream).  Hand-offs between chains are the ones of forward(): main waits for
-        the side chains' blocks before the next cross-condition (eS), side chains wait for x of the layer (eA) before their own
-        cross-condition GEMMs and for main's cross-condition launch (eX) before their blocks overwrite the text / frames buffers it read.
-        Same kernels and arithmetic per problem as forward(): results equal bit for bit whatever the partition
-        (tests/test_sampler_gpu.py::test_grouped_schedule_equals_three_streams)."""
-        p, c, W = self.plan, self.cfg, self.W
-        B, Bt, N, rows = p["B"], p["Bt"], p["N"], p["rows"]
-        D, Dt, Df = c.dim, c.dim_text, c.dim_frames
-        dims = {"a": D, "t": Dt, "f": Df}
-        nctx = B if n_ctx_seqs is None else n_ctx_seqs
-        lens = p["seq_len"] if p["ragged"] else None
-        half = c.depth // 2
-        fz = self._fuse_skip()
-        xc, xo = p["xA"], p["xB"]
-        cur = {"t": p["tL0"], "f": p["fL0"]}                # text / frames entering the layer (layer 0: hoisted into prepare())
-        bufs = {"t": [p["tA"], p["tB"]], "f": [p["fA"], p["fB"]]}
-        tuned = self._regime() == 0 and self._tuned_dims()
-        scale = c.dim_head ** -0.5
-        zq = lens if self.zero_masked_queries else None
-
-        chains = [tuple(ch) for ch in self.chains]
-        assert sorted(s_ for ch in chains for s_ in ch) == ["a", "f", "t"], chains
-        main_chain = next(ch for ch in chains if "a" in ch)
-        side_chains = [ch for ch in chains if "a" not in ch]
-        main = torch.cuda.current_stream()
-        # without side streams in the plan (multi_stream off, or the bench's stand-alone timing) the side chains run on the main stream,
-        # after the main chain of their layer: every kernel alone on the chip
-        multi = p.get("st") is not None
-        side_streams = [p.get("st"), p.get("sf")] if multi else [main, main]
-
-        def hint(chain, op, main_op):
-            """tile_hint of one launch: the measured per-group table while it applies (one clip, shipped widths); a launch of one problem
-            keeps that stream's own choice (audio: _main_hint, sides: _side_hint); otherwise the library picks by the group's shape."""
-            if len(chain) == 1:
-                s_ = chain[0]
-                if s_ == "a":
-                    return self._main_hint(main_op).get("tile_hint", 0)
-                return self._side_hint(s_, {"x_tfa": "cross"}.get(main_op, main_op))
-            if not tuned:
-                return 0
-            table = self.group_tiles_split if self.split else self.group_tiles
-            return table.get(("+".join(chain), op), table.get(op, 0))
-
-        def qkv_args(A, s_):
-            d_ = dims[s_]
-            hn, qkv = p[f"hn_{s_}"], p[f"qkv_{s_}"]
-            return self._mm_args([(hn, d_, d_)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad, rope_table=p["rope"], rope_cols=2 * A.inner,
-                                 rope_pos_offset=0, rows_per_batch=N, **self._ncons(s_, d_))
-
-        def attn_args(A, s_):
-            qkv, ao = p[f"qkv_{s_}"], p[f"ao_{s_}"]
-            es, base, aw = qkv.element_size(), qkv.data_ptr(), ao.stride(-2)
-            return L.attention_args(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
-                                    strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, aw, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * aw),
-                                    B=Bt, H=A.heads, Nq=N, Nk=N, kv_len=lens, q_len=zq, scale=scale, softclamp=self.softclamp, dtype=self.adc,
-                                    out_split=self.split)
-
-        def run_chain(chain, i, ly, nxt, last, x, src, ax, ops_from_cross, eX=None):
-            """The ops of one chain for layer i on the current stream: its cross-condition problems were launched by the caller
-            (`ops_from_cross`), here: conv, QKV, self-attention, out-projection, (audio: cross-attention,) feed-forward in / out."""
-            members = [s_ for s_ in chain if s_ == "a" or not last]            # the last layer has no text / frames blocks
-            if not members:
-                return
-            # position-generating convolutions, each with the RMSNorm after it folded in (x3:1082-1083, 1097-1098, 1122-1126)
-            convs = []
-            for s_ in members:
-                hn = p[f"hn_{s_}"]
-                if s_ == "a":
-                    n0 = self._nprod_ada(i, 0)
-                    cv = ly["a_conv"]
-                    convs.append(dict(x=src, out=x, wt=cv.wt, bias=cv.b, d=D,
-                                      norm=dict(out_bf16=hn, ld_out_bf16=hn.stride(-2), gamma=n0["norm_gamma"], ssq=p["ssq_a"], step=n0.get("step"),
-                                                step_stride=n0.get("norm_step_stride", 0), batch_stride=n0.get("norm_batch_stride", 0), split=self.split)))
-                else:
-                    cv = nxt[f"{s_}_conv"]
-                    convs.append(dict(x=bufs[s_][0], out=bufs[s_][1], wt=cv.wt, bias=cv.b, d=dims[s_],
-                                      norm=dict(out_bf16=hn, ld_out_bf16=hn.stride(-2), gamma=nxt[f"{s_}_g1"], ssq=p[f"ssq_{s_}"], split=self.split)))
-            L.dwconv_grouped(convs, B=Bt, N=N, ksize=ly["a_conv"].k, lens=lens)
-            blk = {s_: ((ly["a_attn"], ly["a_ff"], x) if s_ == "a" else (nxt[f"{s_}_attn"], nxt[f"{s_}_ff"], bufs[s_][1])) for s_ in members}
-            L.gemm_grouped([qkv_args(blk[s_][0], s_) for s_ in members], tile_hint=hint(members, "qkv", "qkv"))
-            L.attention_grouped([attn_args(blk[s_][0], s_) for s_ in members])
-            G = []
-            for s_ in members:
-                A, _, xs = blk[s_]
-                d_, ao, hn = dims[s_], p[f"ao_{s_}"], p[f"hn_{s_}"]
-                if s_ == "a":
-                    r2 = nctx * N
-                    n1 = self._nprod_ada(i, 1, switch_row=r2 if r2 < rows else 0) if nctx > 0 else self._nprod_ada(i, 2)
-                    n1 = {k: v for k, v in n1.items() if k not in ("step", "rows_per_batch")}       # the gate already passes them
-                    kw = dict(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 0), out_bf16=hn, ld_out_bf16=hn.stride(-2), **n1)
-                else:
-                    kw = dict(epilogue=L.EPI_RESID, out_bf16=hn, ld_out_bf16=hn.stride(-2), norm_gamma=nxt[f"{s_}_g2"], norm_ssq=p[f"ssq_{s_}"])
-                G.append(self._mm_args([(ao, A.inner, A.inner)], A.w_out, xs, M=rows, N=d_, resid=xs, ldo=d_, ldr=d_, **kw))
-            L.gemm_grouped(G, tile_hint=hint(members, "out", "out"))
-            # the audio block's cross-attention to the T5 context (conditional half only; nothing to group it with)
-            if "a" in members and nctx > 0:
-                self._audio_cross_attention(i, ly, x, nctx, self._ncons("a", D), True, lens)
-            # feed-forward (x3:817,884,917): GEGLU in, residual out
-            G = []
-            for s_ in members:
-                Fw, d_ = blk[s_][1], dims[s_]
-                hn, ffh = p[f"hn_{s_}"], p[f"ffh_{s_}"]
-                G.append(self._mm_args([(hn, d_, d_)], Fw.w1, ffh, M=rows, N=2 * Fw.inner, epilogue=L.EPI_GEGLU, bias=Fw.b1, ldo=ffh.stride(-2),
-                                       **(dict(out_split=True) if self.split else {}), **self._ncons(s_, d_)))
-            L.gemm_grouped(G, tile_hint=hint(members, "ff1", "ff1"))
-            G = []
-            for s_ in members:
-                _, Fw, xs = blk[s_]
-                d_, ffh = dims[s_], p[f"ffh_{s_}"]
-                if s_ == "a":
-                    # the bf16 copy of this layer's output: into the wide buffer of the next layer's skip when that layer is fused;
-                    # after the last layer it is the operand of to_pred with the final RMSNorm folded in
-                    if last:
-                        kw = dict(out_bf16=p["hn_a"], ld_out_bf16=p["hn_a"].stride(-2), norm_gamma=W.final_g, norm_ssq=p["ssq_a"])
-                    elif fz and half <= i + 1 < c.depth:
-                        sh = p["wide"][c.depth - 2 - i][..., :D]
-                        kw = dict(out_bf16=sh, ld_out_bf16=sh.stride(-2))
-                    else:
-                        kw = dict(out_bf16=self._sh(xs))
-                    kw.update(epilogue=L.EPI_GATE_RESID, **self._gate_kw(i, 2))
-                else:
-                    kw = dict(epilogue=L.EPI_RESID, out_bf16=self._sh(xs))
-                G.append(self._mm_args([(ffh, Fw.inner, Fw.inner)], Fw.w2, xs, M=rows, N=d_, bias=Fw.b2, resid=xs, ldo=d_, ldr=d_, **kw))
-            L.gemm_grouped(G, tile_hint=hint(members, "ff2", "ff2"))
-
-        def rec(stream):
-            if not multi:
-                return None
-            e = torch.cuda.Event()
-            e.record(stream)
-            return e
-
-        def wait(stream, e):
-            if multi and e is not None:
-                stream.wait_event(e)
-
-        eS = []                               # side chains' blocks of the previous layer done
-        eA = rec(main) if side_chains else None      # x of the layer ready (end of the main chain of the previous layer)
-        for i, ly in enumerate(W.layers):
-            last = i == c.depth - 1
-            nxt = None if last else W.layers[i + 1]
-            for e in eS:
-                wait(main, e)
-            xn = p["skips"][i] if i < half else xo
-            ax, at_, af_ = self._opnd(xc), self._opnd(cur["t"]), self._opnd(cur["f"])
-            fused = fz and i >= half
-            if fused:
-                wd = p["wide"][c.depth - 1 - i]
-                ax = wd[..., :D]
-            ax_ld = ax.stride(-2)
-
-            def cross_args(s_):
-                """cross condition (x3:686-702): the three GEMMs read the PRE-update x, text, frames of this layer"""
-                if s_ == "a":
-                    if fused:
-                        return self._mm_args([(wd, 2 * D, 2 * D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_skip"], p["xS"], M=rows, N=D, ldo=D)
-                    return self._mm_args([(ax, D, D), (at_, Dt, Dt), (af_, Df, Df)], ly["x_tfa"], xn, M=rows, N=D, epilogue=L.EPI_RESID, resid=xc,
-                                         ldo=D, ldr=D, out_bf16=self._sh(xn))
-                d_, o_ = dims[s_], self._opnd(cur[s_])
-                return self._mm_args([(ax, ax_ld, D), (o_, d_, d_)], ly["x_at" if s_ == "t" else "x_af"], bufs[s_][0], M=rows, N=d_, epilogue=L.EPI_RESID,
-                                     resid=cur[s_], ldo=d_, ldr=d_)
-
-            mem = [s_ for s_ in main_chain if s_ == "a" or not last]
-            L.gemm_grouped([cross_args(s_) for s_ in mem], tile_hint=hint(mem, "cross", "x_tfa"))
-            # eX: main has read this layer's text / frames buffers -- the side blocks may overwrite them
-            eX = rec(main) if side_chains and not last else None
-            if i < half:
-                src = xn
-            else:
-                src = p["xS"]
-                if not fused:               # (without the fused weights: skip_proj(cat(x, skip)) as its own launch)
-                    sk = self._opnd(p["skips"][c.depth - 1 - i])
-                    self._mm([(self._opnd(xn), D, D), (sk, sk.stride(-2), D)], ly["skip"], src, M=rows, N=D, ldo=D, **self._main_hint("skip"))
-            run_chain(main_chain, i, ly, nxt, last, xo, src, ax, None)
-            eS = []
-            if side_chains and not last:
-                eA_next = rec(main)         # x of the next layer is ready
-                for ch, st_ in zip(side_chains, side_streams):
-                    with torch.cuda.stream(st_):
-                        wait(st_, eA)
-                        L.gemm_grouped([cross_args(s_) for s_ in ch], tile_hint=hint(list(ch), "cross", "cross"))
-                        wait(st_, eX)
-                        run_chain(ch, i, ly, nxt, last, None, None, ax, None)
-                        eS.append(rec(st_))
-                eA = eA_next
-            if not last:
-                cur = {"t": bufs["t"][1], "f": bufs["f"][1]}
-            xc, xo = xo, xc
-        # to_pred with the folded final norm (x3:1141-1143, 2083)
-        self._mm([(p["hn_a"], D, D)], W.pred_w, p["pred"], M=rows, N=c.num_channels, bias=W.pred_b, ldo=c.num_channels, **self._ncons("a", D))
         return p["pred"]
 
     def euler_step(self, y, cfg_strength: float, remove_parallel_component: bool = False, keep_parallel_frac: float = 0.0):

@@ -151,7 +151,7 @@ class E2TTS:
         video_encoder="clip_vit",
         *,
         # ---- build-side extensions (keyword-only) ----
-        compute_dtype: str = "bf16",         # "bf16" | "fp32" (parity mode, exact-fp32 MFMA) | "bf16x3" (parity-grade split-bf16 GEMMs)
+        compute_dtype: str = "bf16x3",       # "bf16x3" (default: split-bf16 GEMMs, inside 1e-3 of the fp32 reference path, config.yaml:7) | "bf16" (2x faster, ~5e-2 off) | "fp32" (exact-fp32 MFMA)
         device="cuda",
         rope_layout: str = "interleaved",
         rope_cross: bool = False,            # x-transformers 1.37.4 ignores rotary_pos_emb when a context is given; True = the other reading
