@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
     ap.add_argument("--no-fuse-skip", action="store_true", help="A/B: cross-condition and skip projection as two GEMMs")
     ap.add_argument("--no-fuse-xattn", action="store_true", help="A/B: q-projection and cross-attention of the audio stream as two launches")
+    ap.add_argument("--no-attn-planes", action="store_true", help="A/B (bf16x3): self-attention splits fp32 q, k, v itself instead of reading the hi | lo planes of the QKV projection's epilogue")
     ap.add_argument("--no-fold-norm", action="store_true", help="A/B: separate RMSNorm launches instead of folding them into the neighbouring kernels")
     ap.add_argument("--big-tiles", default="", help="A/B: the same table for launches of more than two clips, e.g. a.qkv=0,t.ff2=6")
     ap.add_argument("--side-tiles", default="", help="A/B: per-(stream, op) tile configurations of the side-stream GEMMs, e.g. t.qkv=1,f.ff2=2 (ops: cross qkv out ff1 ff2; -1 = library choice)")
@@ -116,18 +117,29 @@ def main():
     ap.add_argument("--no-video2roll", action="store_true", help="skip the supplementary Video2Roll frame-encoder measurement (SURVEY 8f N2)")
     ap.add_argument("--no-vocoder", action="store_true", help="skip the supplementary Encodec-decoder measurement (SURVEY 8f N1)")
     ap.add_argument("--video2roll-frames", type=int, default=251, help="video frames per clip: floor(750 / 3) + 1 (x3:1913)")
+    ap.add_argument("--stand-in-sampler", action="store_true",
+                    help="CPU rehearsal of the N-rank control path (tests/test_dist_gloo.py): no GPU and no HIP library are touched, sample() is a "
+                         "stand-in that returns each clip's global index, the collectives run over gloo.  Everything around it -- sharding, warm-up, "
+                         "barriers, the timed loop, the MAX over ranks, the all-gather, `scaling_reference` -- is this script's real code.  The line "
+                         "says so in `data`; its numbers measure nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)             # rehearsal of N ranks on fewer devices (V2A_BENCH_BACKEND=gloo)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    standin = args.stand_in_sampler
     import torch.distributed as dist
-    backend = os.environ.get("V2A_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+    if standin:
+        dev = torch.device("cpu")
+        backend = "gloo"
+        torch.cuda.synchronize = lambda *a, **k: None          # (this process never touches a GPU)
+    else:
+        ndev = torch.cuda.device_count()
+        local = local % max(ndev, 1)             # rehearsal of N ranks on fewer devices (V2A_BENCH_BACKEND=gloo)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        backend = os.environ.get("V2A_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -138,6 +150,8 @@ def main():
     from v2a_amd import _lib as L
     from v2a_amd.synth import random_state_dict, synthetic_conditioning
 
+    if standin:
+        return standin_main(args, v2a_amd, dist, rank, world)
     if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8 or args.gemm_8phase_min_tiles > 0 or args.attn_one_group_from > 0:
         L.set_tuning(force_tile=args.gemm_force_tile, eight_phase=(args.gemm_8phase if args.gemm_8phase >= 0 else None),
                      eight_phase_min_tiles=args.gemm_8phase_min_tiles, xcd_order_1x8=args.xcd_1x8,
@@ -175,6 +189,8 @@ def main():
         model.engine().fuse_skip = False
     if args.no_fuse_xattn:
         model.engine().fuse_xattn = False
+    if args.no_attn_planes:
+        model.engine().attn_planes = False
     model.engine().cross_on_main = args.cross_on_main
     if args.interleave_capture >= 0:
         model.engine().interleave_capture = bool(args.interleave_capture)
@@ -345,6 +361,62 @@ def main():
         if not args.no_cpu_baseline:
             res.update(cpu_baseline_leg(model, cfg, one_step, y0, text, roll, ctx, cm, args, T))
         res.update(summary_fields(res))
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def standin_main(args, v2a_amd, dist, rank, world):
+    """--stand-in-sampler: the N-rank control path of main() on CPU tensors over gloo (no GPU, no HIP library).  The sampler is replaced by
+    a function that returns, for every clip of the rank's shard, a (T, C) tensor filled with the clip's GLOBAL index; the all-gather must
+    then hand every rank the tensor whose clip i is filled with i, whatever the partition (a batch that does not divide by the world size
+    is padded and the padding dropped).  Sharding follows v2a_amd.shard_range exactly as cli.py does for a real batch."""
+    T, C = 6, 4
+    B = args.clips_per_gpu if args.clips_per_gpu > 0 else (1 if world == 1 else 8)
+    n_clips = int(os.environ.get("V2A_STANDIN_CLIPS", B * world))        # a batch size that need not divide by the world size
+    lo, hi, per = v2a_amd.shard_range(n_clips, rank, world)
+    def sample():
+        time.sleep(0.002 * (1 + rank % 3))                                # ranks finish at different times: the MAX over ranks matters
+        return torch.stack([torch.full((T, C), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros(0, T, C)
+    def one_step():
+        return v2a_amd.gather_latents(sample(), n_clips, per)
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ok = out.shape == (n_clips, T, C) and all(bool((out[i] == float(i)).all()) for i in range(n_clips))
+    frames_per_s = n_clips * T / (el / args.steps)
+    res = {"metric": "stand-in (control-path rehearsal, measures nothing)", "value": round(frames_per_s, 2), "unit": "mel-frames/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "none", "data": "stand-in sampler on CPU tensors over gloo: no GPU work",
+           "config": {"workload": "stand-in", "clips_per_gpu": per, "global_clips": n_clips, "parallelism": "clip-sharded x%d, 1 all-gather" % world},
+           "standin_gather_ok": bool(ok), "standin_shard": [lo, hi, per]}
+    if world > 1:
+        same = None
+        if rank == 0:
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                sample()
+            same = max(hi - lo, 1) * T / ((time.perf_counter() - ts) / args.steps)
+        dist.barrier()
+        if rank == 0:
+            res["scaling_reference"] = scaling_reference(per, same, frames_per_s, world)
+    oks = [None] * world
+    if world > 1:
+        dist.all_gather_object(oks, bool(ok))
+        res["standin_gather_ok_all_ranks"] = all(oks)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -139,6 +139,10 @@ typedef struct v2a_gemm_args {
    * v2a_split_bf16 pass.  Likewise out_dtype = V2A_BF16_SPLIT (GEGLU epilogue only): out row m = [hi | lo] planes of the N/2
    * hidden values, ldo >= N, exact erf GELU. */
   int32_t out_bf16_split;
+  /* ABI 8: columns [0, out_skip_cols) of the result go to the out_bf16 shadow only, `out` keeps what it held there (a multiple of 4; needs an
+   * fp32 `out` with a shadow; vector epilogues).  The bf16x3 mode's fused [q | k | v | gate] projection: q, k, v are consumed as hi | lo planes
+   * by v2a_attention (qkv_lo_offset), only the gate columns are read as fp32. */
+  int32_t out_skip_cols;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
@@ -241,6 +245,10 @@ typedef struct v2a_attn_args {
   int32_t out_split;     /* dtype V2A_BF16_SPLIT only, non-zero: out is a bf16 buffer in the V2A_BF16_SPLIT layout -- row =
                           * [hi of the H*64 outputs | lo of them], out_row_stride / out_batch_stride in bf16 elements -- i.e. the
                           * A operand of the out-projection's split GEMM, written directly */
+  int64_t qkv_lo_offset; /* ABI 8, dtype V2A_BF16_SPLIT with out_split: > 0 = q, k and v point at the bf16 HI planes of a split row and the lo
+                          * planes lie qkv_lo_offset elements further (the out_bf16_split shadow of the fused [q | k | v | gate] projection:
+                          * ld_out_bf16 = 2 * N, lo offset N); their strides are then in bf16 elements; gate stays fp32.  Same result as
+                          * the fp32 inputs those planes were made from, bit for bit, without the conversion of every K / V tile */
 } v2a_attn_args;
 
 int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);
@@ -302,8 +310,12 @@ int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t T, int32_t
                    v2a_stream_t stream);
 int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C,
                   int64_t pred_batch_stride, int32_t row_off, float cfg_strength,
-                  const float* dt, const int32_t* step, const double* apg,
-                  float keep_parallel_frac, v2a_stream_t stream);
+                  const float* dt, int32_t* step, const double* apg,
+                  float keep_parallel_frac,
+                  int32_t* arrival /* ABI 8: NULL, or one zeroed device int private to the stream: the launch then ALSO advances the step
+                                      counter (step[0] += 1 by the last of its blocks to have used it; the count re-arms itself) -- the
+                                      v2a_step_advance launch behind every evaluation is not needed */,
+                  v2a_stream_t stream);
 /* y[r][0:d] = hi, y[r][d:2d] = lo of x[r][0:d] (V2A_BF16_SPLIT layout above), rows x d fp32 in, row strides in elements,
  * d % 4 == 0: the split operand copy of an fp32 buffer (residual streams, attention outputs, GEGLU hidden) for the
  * three-segment bf16 GEMMs of the bf16x3 mode */
@@ -311,7 +323,7 @@ int v2a_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t ro
 /* y[i] = bf16(x[i]), n % 4 == 0: bf16 operand copy of an fp32 stream that no GEMM epilogue produced
  * (the embed output x3:2027 feeding the first cross-condition GEMM) */
 int v2a_cast_bf16(const float* x, void* y, int64_t n, v2a_stream_t stream);
-/* step[0] += 1 (own launch: every block of the step has read step[0] before it runs) */
+/* step[0] += 1 as a launch of its own (callers that do not pass `arrival` to v2a_cfg_euler) */
 int v2a_step_advance(int32_t* step, v2a_stream_t stream);
 
 /* =======================================================================================

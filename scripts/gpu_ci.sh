@@ -102,10 +102,10 @@ for s in "$@"; do
            TAILN=0 run m1_x 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder $v
            echo "--- [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/m1_x.log | head -1) batched $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/m1_x.log | head -1)"
          done ;;
-    x3tiles) for v in "_" "t.cross=0,t.out=0,t.ff2=0,t.ff1=0,a.ff1=-1,a.qkv=-1,f.ff1=0,f.qkv=0" "t.ff1=0,a.ff1=-1,f.ff1=0,f.qkv=0" "a.qkv=-1" "_"; do
+    x3tiles) for v in ${X3T_SWEEP:-"_" "a.qkv=4,t.qkv=4" "a.qkv=6,t.qkv=6" "a.qkv=6,t.qkv=6,t.ff1=6" "a.qkv=6,t.qkv=6,t.ff1=3" "a.qkv=6,t.qkv=6,t.ff1=6,a.ff1=6,f.ff1=6" "_"}; do
            a=""; [ "$v" != "_" ] && a="--side-tiles $v"
-           TAILN=0 run x3_x 300 python bench.py --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder --no-batched $a
-           echo "--- bf16x3 side tiles [$v]: $(grep -o '"value": [0-9.]*' gpurun_out/x3_x.log | head -1)"
+           TAILN=0 run x3_x 300 python bench.py --dtype bf16x3 --steps ${X3T_STEPS:-5} --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder ${X3T_EXTRA:---no-batched} $a
+           echo "--- bf16x3 tiles [$v] ${X3T_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/x3_x.log | head -1) $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/x3_x.log | head -1)"
          done ;;
     prof_modes) for m in bf16x3 fp32; do
            rm -rf /tmp/profm; run prof_$m 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profm -- python bench.py --dtype $m --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs
@@ -147,6 +147,17 @@ for s in "$@"; do
           mkdir -p gpurun_out/prof; cp /tmp/prof1/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_singlestream.csv ;;
     prof_v2r) rm -rf /tmp/profv; run prof_v2r 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profv -- python bench.py --steps 1 --warmup 0 --cfm-steps 4 --no-cpu-baseline --no-roofline --no-batched
           mkdir -p gpurun_out/prof; cp /tmp/profv/*/*_kernel_stats.csv gpurun_out/prof/kernel_stats_video2roll.csv ;;
+    q1) # quick one-clip / 8-clip throughput of the headline mode (or DT=...): no extras
+        TAILN=0 run q1$DTS 300 python bench.py $DTA --steps ${Q_STEPS:-5} --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder ${Q_EXTRA:-}
+        echo "--- q1 ${DT:-bf16x3} ${Q_EXTRA:-}: one clip $(grep -o '"value": [0-9.]*' gpurun_out/q1$DTS.log | head -1)  8 clips $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/q1$DTS.log | head -1)" ;;
+    sprobe) TAILN=60 run sprobe${SP_TAG:-} 900 python scripts/split_probe.py ${SP_ARGS:-} ;;
+    ksplit) run ksplit 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "split" ;;
+    ab) # generic A/B of bench flags, alternating: AB_A="" AB_B="--flag" [AB_EXTRA="--clips-per-gpu 8"] [AB_N=2]
+        for i in $(seq 1 ${AB_N:-2}); do for v in "${AB_A:-}" "${AB_B:-}"; do
+          TAILN=0 run ab_x 400 python bench.py $DTA --steps ${AB_STEPS:-5} --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-video2roll --no-vocoder ${AB_EXTRA:---no-batched} $v
+          echo "--- ab [$v] ${AB_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/ab_x.log | head -1) $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/ab_x.log | head -1)"
+        done; done ;;
+    kattn) run kattn 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "attention or cfg_euler" ;;
     *) echo "unknown step $s" ;;
   esac
 done

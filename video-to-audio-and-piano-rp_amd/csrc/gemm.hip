@@ -193,16 +193,27 @@ __device__ __forceinline__ void ring_wait(int younger) {
 // (Round 4 measured a software-pipelined form of the K loop -- the fragment reads of tile k + 1 issued behind the barrier of step k into a
 // second register set, landing under the MFMAs of tile k: 1-5 % SLOWER at equal occupancy, 16-27 % where the extra registers cost a
 // resident workgroup, profiles/r04_ring_pipe_probe.txt.  The exposed part of a K step is not the LDS read latency; the form is not kept.)
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false>
+// BK (round 5): K extent of a ring stage, 64 or 32.  With 32 the LDS rows are 64 B -- a 1 KB DMA instruction then covers 16 rows, the
+// 16-B chunk index of a row is XOR-ed with 3 for rows 8..15 of each 16-row group (conflict-free for the lane groups of ds_read_b128:
+// every 16 lanes of a group then cover all 16 slots of a 256-B bank row) -- and a stage holds half the bytes: the split-operand 128x256
+// tile (hi + lo planes) fits three stages in 144 KB and the 64x128 one leaves room for a second workgroup on the CU.
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const GemmParams p) {
+  static_assert(BK == 64 || BK == 32, "K extent of a stage");
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr int PLANE_BYTES = (BM + BN) * 128;            // one A tile + one W tile of a K step
+  constexpr int ROWB = BK * 2;                            // bytes of an LDS row
+  constexpr int RPG = 1024 / ROWB;                        // rows per DMA instruction (1 KB per wave-instruction)
+  constexpr int CPR = BK / 8;                             // 16-B chunks per row
+  constexpr int KK = BK / 32;                             // MFMA K steps per stage
+  constexpr int PLANE_BYTES = (BM + BN) * ROWB;           // one A tile + one W tile of a K step
   constexpr int STAGE_BYTES = PLANE_BYTES * (S3 ? 2 : 1); // S3: [A_hi | W_hi | A_lo | W_lo]
-  constexpr int GA = BM / 8, GW = BN / 8;       // 8-row DMA groups of the A and W tiles
+  constexpr int GA = BM / RPG, GW = BN / RPG;   // DMA groups (RPG rows each) of the A and W tiles
   constexpr int LPW = (GA + GW) / NW;           // DMA instructions per wave per K tile
   static_assert((GA + GW) % NW == 0, "DMA groups must divide evenly over the waves");
+  // chunk swizzle of a row inside its DMA group (applied to the DMA source address and to the fragment reads)
+  auto swz = [](int row) { return BK == 64 ? (row & 7) : (((row >> 3) & 1) * 3); };
   static_assert(EPI != V2A_EPI_GEGLU || (TN % 2 == 0), "GEGLU needs value/gate tile pairs");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
@@ -226,8 +237,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
   // DMA group g (0 .. GA+GW-1) is handled by wave g % NW; groups < GA are A rows, the rest W rows.
   // Each slot keeps ONE 32-bit per-lane byte offset for the whole K loop; the K advance and the
   // operand base are wave-uniform (SGPR), so an issue costs no vector address arithmetic.
-  const int srow = lane >> 3;
-  const int schunk = ((lane & 7) ^ srow) << 3;  // logical chunk (elements) fetched into physical slot lane & 7
+  const int srow = lane / CPR;
+  const int schunk = ((lane % CPR) ^ swz(srow)) << 3;  // logical chunk (elements) fetched into physical slot lane % CPR
   int grow[LPW];
   uint32_t goff[LPW];
   auto set_offsets = [&](int64_t lda) {
@@ -242,10 +253,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
   for (int i = 0; i < LPW; ++i) {
     const int g = wave + i * NW;
     if (g < GA) {
-      const int r = m0 + g * 8 + srow;
+      const int r = m0 + g * RPG + srow;
       grow[i] = r < p.M ? r : p.M - 1;
     } else {
-      const int r = n0 + (g - GA) * 8 + srow;
+      const int r = n0 + (g - GA) * RPG + srow;
       grow[i] = r < p.N ? r : p.N - 1;
     }
   }
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
   const char* const a_first = a_run;
   const int nseg = p.nseg;
   int seg = 0;
-  int seg_left = (nseg > 1 ? p.kend[0] : p.K) >> 6;       // K tiles left in the current segment
+  int seg_left = (nseg > 1 ? p.kend[0] : p.K) / BK;       // K tiles left in the current segment
   // S3: byte offset of the lo plane inside an A row (= the segment's K extent) and inside a W row (= K)
   int64_t a_lo_bytes = S3 ? (int64_t)(nseg > 1 ? p.kend[0] : p.K) * 2 : 0;
   const int64_t w_lo_bytes = S3 ? (int64_t)p.K * 2 : 0;
@@ -275,8 +286,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
     if (seg_left == 0) {                                  // at most twice per kernel: the next A segment has its own base and row stride
       ++seg;
       a_run = reinterpret_cast<const char*>(seg == 1 ? p.a[1] : p.a[2]);
-      seg_left = (seg == 1 ? (nseg > 2 ? p.kend[1] : p.K) - p.kend[0] : p.K - p.kend[1]) >> 6;
-      if constexpr (S3) a_lo_bytes = (int64_t)seg_left * 128;
+      seg_left = (seg == 1 ? (nseg > 2 ? p.kend[1] : p.K) - p.kend[0] : p.K - p.kend[1]) / BK;
+      if constexpr (S3) a_lo_bytes = (int64_t)seg_left * ROWB;
       set_offsets(seg == 1 ? p.lda[1] : p.lda[2]);
     }
     const char* ab = a_run;
@@ -305,8 +316,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
                                            (__attribute__((address_space(3))) void*)(st + PLANE_BYTES + g * 1024), 16, 0, 0);
       }
     }
-    a_run += 128;
-    w_run += 128;
+    a_run += ROWB;
+    w_run += ROWB;
     --seg_left;
     ++kt_next;
   };
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
   const bool scaled = p.rssq != nullptr && p.vec_epi;
   RowScaleLoad rsl;
   if (scaled && tid < BM) rowscale_load(p, m0 + tid, rsl);
-  const int nk = p.K / 64;
+  const int nk = p.K / BK;
   // ring of NST stages, NST - 1 K tiles in flight while one is computed (3 by default; 2: the 256x256 tile, whose 64 KB
   // stages leave room for only two; 6: the small tiles of a one-clip launch, which has at most one workgroup per CU and is
   // bound by DMA latency x bytes in flight -- a K step of the 3-deep 64x64 ring took 1020 cycles for 128 cycles of MFMA)
@@ -340,44 +351,44 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
     ring_wait<NST - 2 < 0 ? 0 : NST - 2, LPW * (S3 ? 2 : 1)>(nk - 1 - kt);
     __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1) % NST
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
-    const bf16_t* Ws = As + BM * 64;
-    // both 32-wide K halves of the tile are requested before the first MFMA: the second half's LDS latency runs under the
-    // first half's MFMA cluster instead of being exposed (the compiler otherwise emits read / wait / MFMA per half)
-    bf16x8 af[2][TM], bf[2][TN];
+    const bf16_t* Ws = As + BM * BK;
+    // all 32-wide K steps of the tile are requested before the first MFMA: the later ones' LDS latency runs under the
+    // first one's MFMA cluster instead of being exposed (the compiler otherwise emits read / wait / MFMA per step)
+    bf16x8 af[KK][TM], bf[KK][TN];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * WM + i * 16 + lr;
-        af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+        af[kk][i] = *reinterpret_cast<const bf16x8*>(As + row * BK + (((kk * 4 + lq) ^ swz(row)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WN + j * 16 + lr;
-        bf[kk][j] = *reinterpret_cast<const bf16x8*>(Ws + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+        bf[kk][j] = *reinterpret_cast<const bf16x8*>(Ws + row * BK + (((kk * 4 + lq) ^ swz(row)) << 3));
       }
     }
     if constexpr (S3) {
       // lo planes of the same rows; three products per fragment pair, small terms first
       const bf16_t* Al = As + PLANE_BYTES / 2;
-      const bf16_t* Wl = Al + BM * 64;
-      bf16x8 afl[2][TM], bfl[2][TN];
+      const bf16_t* Wl = Al + BM * BK;
+      bf16x8 afl[KK][TM], bfl[KK][TN];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int row = wm * WM + i * 16 + lr;
-          afl[kk][i] = *reinterpret_cast<const bf16x8*>(Al + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+          afl[kk][i] = *reinterpret_cast<const bf16x8*>(Al + row * BK + (((kk * 4 + lq) ^ swz(row)) << 3));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int row = wn * WN + j * 16 + lr;
-          bfl[kk][j] = *reinterpret_cast<const bf16x8*>(Wl + row * 64 + (((kk * 4 + lq) ^ (row & 7)) << 3));
+          bfl[kk][j] = *reinterpret_cast<const bf16x8*>(Wl + row * BK + (((kk * 4 + lq) ^ swz(row)) << 3));
         }
       }
       if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
     // (~4 x LPW scalar instructions and LPW address translations) instead of after it
     if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
     // pin that order (the scheduler otherwise sinks the second half's reads back below the first MFMA cluster):
     // [first half's reads] [the DMA issue] then {a few MFMAs, one read of the second half} ... then the remaining MFMAs
-    {
+    if constexpr (BK == 64) {
       constexpr int NL = TM + TN, NM = TM * TN, PER = NM / NL > 0 ? NM / NL : 1;
       __builtin_amdgcn_sched_group_barrier(0x100, NL, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, LPW, 0);
@@ -438,17 +449,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
   }
 }
 
-template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST, bool S3 = false>
+template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST, bool S3 = false, int BK = 64>
 int launch_dma(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
   v2a_detail::fill_tile_map(p, BM, BN);
   V2A_REQUIRE((int64_t)p.tiles_m * p.tiles_n < (1 << 24), "v2a_gemm: %d x %d tiles exceed the tile map", p.tiles_m, p.tiles_n);
-  constexpr size_t smem = NST * (size_t)(BM + BN) * 128 * (S3 ? 2 : 1) + BM * 4 + 16;    // the ring + one row scale per tile row (folded RMSNorm)
+  constexpr size_t smem = NST * (size_t)(BM + BN) * (BK * 2) * (S3 ? 2 : 1) + BM * 4 + 16;    // the ring + one row scale per tile row (folded RMSNorm)
   static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   // W loads keep the default cache policy: non-temporal (aux = 2) measured 9 % slower end to end here, the W
   // panel being re-read from L2 by the 13-25 M-band workgroups of its XCD (profiles/ notes in DESIGN.md)
-  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3>;
+  auto kern = gemm_bf16_dma_kernel<EPI, OutT, BM, BN, WGM, WGN, NST, S3, BK>;
+  if constexpr (BK != 64) V2A_REQUIRE(!p.a_koff, "v2a_gemm(dma): K-tile offset tables are laid out for 64-wide K tiles");
   static std::atomic<uint64_t> lds_set{0};
   if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_gemm(dma)")) return rc;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WGM * WGN), smem, s, p);
@@ -476,23 +488,23 @@ int dispatch_dma(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
 }
 
 // split-bf16 operands (bf16x3 mode): the epilogues that mode uses
-template <int BM, int BN, int WGM, int WGN, int NST>
+template <int BM, int BN, int WGM, int WGN, int NST, int BK = 64>
 int dispatch_s3(const v2a_gemm_args* a, const GemmParams& p, hipStream_t s) {
   const bool out_f32 = a->out_dtype == V2A_F32;
   switch (a->epilogue) {
     case V2A_EPI_STORE:
-      if (out_f32) return launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST, true>(p, s);
+      if (out_f32) return launch_dma<V2A_EPI_STORE, float, BM, BN, WGM, WGN, NST, true, BK>(p, s);
       break;
     case V2A_EPI_GEGLU:
       if constexpr ((BN / WGN / 16) % 2 == 0) {
-        if (a->out_dtype == V2A_BF16_SPLIT) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST, true>(p, s);
+        if (a->out_dtype == V2A_BF16_SPLIT) return launch_dma<V2A_EPI_GEGLU, bf16_t, BM, BN, WGM, WGN, NST, true, BK>(p, s);
       }
       break;
     case V2A_EPI_RESID:
-      if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN, NST, true>(p, s);
+      if (out_f32) return launch_dma<V2A_EPI_RESID, float, BM, BN, WGM, WGN, NST, true, BK>(p, s);
       break;
     case V2A_EPI_GATE_RESID:
-      if (out_f32) return launch_dma<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST, true>(p, s);
+      if (out_f32) return launch_dma<V2A_EPI_GATE_RESID, float, BM, BN, WGM, WGN, NST, true, BK>(p, s);
       break;
   }
   return v2a_fail(V2A_ERR_ARG, "v2a_gemm(split bf16): unsupported epilogue %d / out_dtype %d for this tile shape", a->epilogue, a->out_dtype);
@@ -584,6 +596,7 @@ static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
   p.ldo2 = a->ld_out_bf16;
   if (a->out_bf16) V2A_REQUIRE(a->out_dtype == V2A_F32 && a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: out_bf16 shadows an fp32 output only");
   p.out2_split = a->out_bf16 && a->out_bf16_split ? 1 : 0;
+  p.out_skip = a->out_skip_cols;
   if (p.out2_split) V2A_REQUIRE(a->ld_out_bf16 >= 2 * (int64_t)a->N, "v2a_gemm: a split shadow needs ld_out_bf16 >= 2 * N");
   p.out_split = a->out_dtype == V2A_BF16_SPLIT ? 1 : 0;
   if (p.out_split) V2A_REQUIRE(a->epilogue == V2A_EPI_GEGLU && a->ldo >= a->N, "v2a_gemm: out_dtype V2A_BF16_SPLIT goes with the GEGLU epilogue and ldo >= N");
@@ -605,6 +618,10 @@ static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
     if (a->out_bf16) ok = ok && ((uintptr_t)a->out_bf16 & 7) == 0 && a->ld_out_bf16 % 4 == 0;
     p.vec_epi = ok ? 1 : 0;
   }
+  V2A_REQUIRE(a->out_skip_cols >= 0 && a->out_skip_cols % 4 == 0 &&
+                  (a->out_skip_cols == 0 || (a->out_bf16 && a->out_dtype == V2A_F32 && p.vec_epi && a->compute_dtype == V2A_BF16 && a->a_dtype != V2A_F32)),
+              "v2a_gemm: out_skip_cols (%d) is a multiple of 4 and goes with bf16 / split operands, an fp32 output with an out_bf16 shadow and "
+              "16-byte aligned epilogue operands", a->out_skip_cols);
   p.relu = a->relu;
   // off by default: +0.7 % throughput, but the fp32 summation order of a row then depends on how many rows the call has, so a
   // clip's result would change (in the last bits) with the batch it is sampled in; v2a_set_tuning enables it
@@ -695,10 +712,12 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   }
   if (split_in) {
     V2A_REQUIRE(p.vec_epi && !a->a_row_offset && !a->out_row_offset, "v2a_gemm: split operands need dense rows and 16-byte aligned epilogue operands");
-    V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 5, "v2a_gemm: tile_hint %d with split operands (0 = by shape, 1..5)", a->tile_hint);
+    V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 9, "v2a_gemm: tile_hint %d with split operands (0 = by shape, 1..9)", a->tile_hint);
     auto nt = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
     // split-operand tile shapes (hi + lo planes double a stage): 1 = 64x64 (96 KB), 2 = 128x64 (144 KB), 3 = 128x128 with 8 waves and a
-    // 2-deep ring (128 KB), 4 = 64x128 with 8 waves (144 KB)
+    // 2-deep ring (128 KB), 4 = 64x128 with 8 waves (144 KB), 5 = the 8-phase kernel; with 32-wide K stages (round 5): 6 = 128x256 with
+    // 8 waves (wave tile 64x64; 3 stages of 48 KB), 7 = 64x128 with 4 waves (3 stages of 24 KB: two workgroups per CU), 8 = 128x128 with
+    // 8 waves (3 stages of 32 KB), 9 = 64x128 with 4 waves and 4 stages (96 KB)
     int cfg = a->tile_hint;
     // the phase-interleaved 256x256 kernel on three passes over the logical K (hi x hi, hi x lo, lo x hi; it re-reads A_hi and W_hi, but
     // its K loop hides the operand stream behind the MFMAs): wide outputs from 150 tiles (audio feed-forward at one clip: 76 us against
@@ -715,13 +734,21 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
       return v2a_detail::launch_gemm_8phase(q, a->epilogue, a->out_dtype == V2A_BF16_SPLIT ? V2A_BF16 : a->out_dtype, s);
     }
     if (cfg == 0) {
+      // (stand-alone, scripts/split_probe.py, profiles/r05_split_probe.txt)
       if (a->epilogue == V2A_EPI_GEGLU || a->N >= 2048) cfg = nt(128, 128) >= 200 ? 3 : 4;
+      // N <= 512 with many rows (the frames stream at 8 clips per GPU: 98 tiles of 256x256 cannot fill the chip on the 8-phase kernel):
+      // 128x256 tiles on 32-wide K stages, 960 against 721 TF/s (64x128) at 12512x512x2048
+      else if (a->N <= 512 && nt(128, 256) >= 128) cfg = 6;
       else cfg = nt(64, 128) >= 160 ? 4 : 1;
     }
     switch (cfg) {
       case 1: return dispatch_s3<64, 64, 2, 2, 3>(a, p, s);
       case 2: return dispatch_s3<128, 64, 2, 2, 3>(a, p, s);
       case 3: return dispatch_s3<128, 128, 2, 4, 2>(a, p, s);
+      case 6: return dispatch_s3<128, 256, 2, 4, 3, 32>(a, p, s);
+      case 7: return dispatch_s3<64, 128, 2, 2, 3, 32>(a, p, s);
+      case 8: return dispatch_s3<128, 128, 2, 4, 3, 32>(a, p, s);
+      case 9: return dispatch_s3<64, 128, 2, 2, 4, 32>(a, p, s);
       default: return dispatch_s3<64, 128, 2, 4, 3>(a, p, s);
     }
   }

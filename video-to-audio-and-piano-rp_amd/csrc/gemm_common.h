@@ -57,6 +57,7 @@ struct GemmParams {
   // split (hi | lo plane) outputs of the bf16x3 mode: out2 = the shadow (lo plane N columns after hi), out = the GEGLU hidden
   // (lo plane N / 2 columns after hi)
   int32_t out2_split, out_split;
+  int32_t out_skip;         // columns [0, out_skip) are not written to `out` (their values travel in the out2 shadow only)
   // 8-phase kernel, split (hi | lo plane) operands: s3_kl = the LOGICAL K (sum of the segments' extents), K = 3 * s3_kl, and the K loop
   // walks the logical K three times: pass 0 = A_hi x W_hi, pass 1 = A_hi x W_lo, pass 2 = A_lo x W_hi -- every pass over all (up to
   // three) logical segments, whose rows are [hi k | lo k] (lda >= 2k), against weight rows [W_hi (s3_kl) | W_lo (s3_kl)].  0 = plain operands
@@ -430,11 +431,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c4;
         if constexpr (sizeof(OutT) == 2) {
           if (p.out_split) {
-            // bf16x3 mode: exact erf GELU in fp32, stored as hi | lo planes (lo plane N / 2 columns further)
+            // bf16x3 mode: fp32 GELU stored as hi | lo planes (lo plane N / 2 columns further).  erf by Abramowitz-Stegun 7.1.26
+            // (|error| <= 1.5e-7, two orders below the 2^-17 the planes keep): libm's branchy erff cost ~20 us per 256x256 tile round
+            // here against ~6 (64 values per lane), a fifth of a feed-forward launch at 8 clips per GPU
             bf16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float o32 = (v[e] + bv[e]) * gelu_erf_f(g[e] + bg[e]);
+              const float o32 = (v[e] + bv[e]) * gelu_fast_f(g[e] + bg[e]);
               hi[e] = (bf16_t)o32;
               lo[e] = (bf16_t)(o32 - (float)hi[e]);
             }
@@ -522,7 +525,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
           for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
           *reinterpret_cast<bf16x4*>(out + o_out + n) = o;
         } else {
-          *reinterpret_cast<f32x4*>(out + o_out + n) = v;
+          if (n >= p.out_skip) *reinterpret_cast<f32x4*>(out + o_out + n) = v;
           if (out2) {
             // folded RMSNorm, producer side: the shadow carries the norm's gamma (the consumer applies 1 / rms per row) and
             // the row's sum of squares is left per 32 columns (8 lanes x 4 columns: a butterfly inside the lane octet)

@@ -296,6 +296,9 @@ class DiTEngine:
         # bf16 and bf16x3 modes, up to three clips (bf16 stand-alone: 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
         # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
         self.fuse_xattn = True
+        # bf16x3 mode: self-attention reads q, k, v as the hi | lo planes the QKV projection's epilogue writes (False: fp32 q, k, v split in
+        # the attention kernel; equal bit for bit, A/B)
+        self.attn_planes = True
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
@@ -355,6 +358,8 @@ class DiTEngine:
             # folded RMSNorm: sums of squares per 32 columns of the row to be normed; rows padded with zeros to whole float4
             p[f"ssq_{s}"] = torch.zeros(rows, (d // 32 + 3) // 4 * 4, device=dev)
             p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=self.ad)
+            if self.split:      # bf16x3: q, k, v as hi | lo planes written by the QKV projection's epilogue (the attention kernel's operands)
+                p[f"qkvp_{s}"] = e(rows, 2 * attn.n_pad, dt=cd)
             p[f"ao_{s}"] = e(rows, w2 * attn.inner, dt=cd)
             p[f"ffh_{s}"] = e(rows, w2 * ff.inner, dt=cd)
         # bf16 shadows of the fp32 residual streams (written by the producing GEMM epilogues): the
@@ -385,7 +390,9 @@ class DiTEngine:
         p["gate_tab"] = e(S, c.depth, 3, D)
         p["t_pts"] = e(S)
         p["dt"] = e(S)
-        p["step"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        # [step counter | arrival count of v2a_cfg_euler, which advances the counter itself]
+        p["step2"] = torch.zeros(2, dtype=torch.int32, device=dev)
+        p["step"], p["arrival"] = p["step2"][:1], p["step2"][1:]
         p["apg"] = torch.zeros(2 * B, dtype=torch.float64, device=dev)
         # latent frames of the CALL (<= T when the plan is padded to a shape bucket): the APG sums of x3:162-173 run over the call's own
         # (b, n, C) tensor, not over padding rows.  A device int -- a captured graph bakes scalar arguments, and one graph serves a bucket
@@ -417,7 +424,7 @@ class DiTEngine:
         the tuning knobs on this object and the per-call state prepare() leaves in the plan."""
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
-                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
+                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.attn_planes, self.cross_on_main,
                 self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
@@ -514,9 +521,13 @@ class DiTEngine:
         p = self.plan
         N, rows = p["N"], nseq * p["N"]
         hn, qkv, ao = p[f"hn_{s}"], p[f"qkv_{s}"], p[f"ao_{s}"]
+        # bf16x3: the epilogue also writes the row as hi | lo bf16 planes, which the split attention kernel stages as they are (no fp32 ->
+        # plane conversion of every K / V tile; same result bit for bit); only the gate columns are then needed in fp32
+        planes = p.get(f"qkvp_{s}") if (self.split and self.attn_planes and self._fuse_rope) else None
+        pk = dict(out_bf16=planes, ld_out_bf16=2 * A.n_pad, out_skip_cols=A.gate_col) if planes is not None else {}
         if self._fuse_rope:       # RoPE of the q and k heads inside the QKV GEMM epilogue
             self._mm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad,
-                     rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **in_kw)
+                     rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **pk, **in_kw)
         else:
             self._mm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad, **in_kw)
             L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
@@ -525,12 +536,19 @@ class DiTEngine:
         base = qkv.data_ptr()
         lens = p["seq_len"] if p["ragged"] else None
         aw = ao.stride(-2)                      # inner, or 2 * inner in bf16x3 mode: the kernel writes hi | lo planes itself
-        L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
-                    strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, aw,
-                             N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * aw),
-                    B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens,
-                    q_len=lens if self.zero_masked_queries else None,
-                    scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
+        if planes is not None:
+            pb, pw = planes.data_ptr(), 2 * A.n_pad
+            L.attention(pb, pb + A.inner * 2, pb + 2 * A.inner * 2, base + A.gate_col * es, ao.data_ptr(),
+                        strides=(pw, pw, pw, A.n_pad, aw, N * pw, N * pw, N * pw, N * A.n_pad, N * aw),
+                        B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens, q_len=lens if self.zero_masked_queries else None,
+                        scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=True, qkv_lo_offset=A.n_pad)
+        else:
+            L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
+                        strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, aw,
+                                 N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * aw),
+                        B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens,
+                        q_len=lens if self.zero_masked_queries else None,
+                        scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
         self._mm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, resid=x, ldo=d, ldr=d, **out_kw)
 
     def _ff(self, Fw: _FF, x, s, nseq, d, out_kw, in_kw={}):
@@ -950,5 +968,5 @@ class DiTEngine:
         if remove_parallel_component:
             L.apg_reduce(p["pred"], p["apg"], valid_rows=p["valid_T"], **kw)
             apg = p["apg"]
-        L.cfg_euler(y, p["pred"], cfg_strength=cfg_strength, dt=p["dt"], step=p["step"], apg=apg, keep=keep_parallel_frac, **kw)
-        L.step_advance(p["step"])
+        # (the launch also advances the step counter: its last block to arrive increments it)
+        L.cfg_euler(y, p["pred"], cfg_strength=cfg_strength, dt=p["dt"], step=p["step"], apg=apg, keep=keep_parallel_frac, arrival=p["arrival"], **kw)
