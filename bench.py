@@ -95,12 +95,12 @@ def main():
     ap.add_argument("--gemm-8phase", type=int, default=-1, help="v2a_set_tuning: 256x256 phase-interleaved GEMM kernel (-1 library default, 0 off, 1 staggered, 2 lock-step)")
     ap.add_argument("--gemm-8phase-min-tiles", type=int, default=0, help="v2a_set_tuning: minimum 256x256 tile count for that kernel (0 = library default)")
     ap.add_argument("--gemm-force-tile", type=int, default=-1, help="v2a_set_tuning: one tile configuration for every bf16 GEMM (experiment)")
+    ap.add_argument("--tuning-reserved", type=int, default=0, help="v2a_tuning.reserved[0] (A/B bits: 128 = GEGLU epilogue with 8-byte stores)")
     ap.add_argument("--xcd-1x8", action="store_true", help="A/B: round-1 XCD tile order (column strips) instead of the per-shape rectangle grid")
     ap.add_argument("--interleave-capture", type=int, default=-1, help="A/B: 1 = interleave the capture order of audio and side blocks")
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
     ap.add_argument("--no-fuse-skip", action="store_true", help="A/B: cross-condition and skip projection as two GEMMs")
     ap.add_argument("--no-fuse-xattn", action="store_true", help="A/B: q-projection and cross-attention of the audio stream as two launches")
-    ap.add_argument("--no-attn-planes", action="store_true", help="A/B (bf16x3): self-attention splits fp32 q, k, v itself instead of reading the hi | lo planes of the QKV projection's epilogue")
     ap.add_argument("--no-fold-norm", action="store_true", help="A/B: separate RMSNorm launches instead of folding them into the neighbouring kernels")
     ap.add_argument("--big-tiles", default="", help="A/B: the same table for launches of more than two clips, e.g. a.qkv=0,t.ff2=6")
     ap.add_argument("--side-tiles", default="", help="A/B: per-(stream, op) tile configurations of the side-stream GEMMs, e.g. t.qkv=1,f.ff2=2 (ops: cross qkv out ff1 ff2; -1 = library choice)")
@@ -152,10 +152,10 @@ def main():
 
     if standin:
         return standin_main(args, v2a_amd, dist, rank, world)
-    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8 or args.gemm_8phase_min_tiles > 0 or args.attn_one_group_from > 0:
+    if args.gemm_8phase >= 0 or args.gemm_force_tile >= 0 or args.xcd_1x8 or args.gemm_8phase_min_tiles > 0 or args.attn_one_group_from > 0 or args.tuning_reserved:
         L.set_tuning(force_tile=args.gemm_force_tile, eight_phase=(args.gemm_8phase if args.gemm_8phase >= 0 else None),
                      eight_phase_min_tiles=args.gemm_8phase_min_tiles, xcd_order_1x8=args.xcd_1x8,
-                     attn_one_group_from=args.attn_one_group_from)
+                     attn_one_group_from=args.attn_one_group_from, reserved=args.tuning_reserved)
     cfg = v2a_amd.DiTConfig()
     if args.clips_per_gpu <= 0:
         args.clips_per_gpu = 1 if world == 1 else 8
@@ -178,7 +178,7 @@ def main():
     if args.main_tile >= 0:
         model.engine().main_tile = args.main_tile
     # (bf16x3 mode: --side-tiles addresses the split-operand tile table: 1 = 64x64, 2 = 128x64, 3 = 128x128 / 8 waves, 4 = 64x128 / 8 waves, 5 = 8-phase)
-    for spec, table in ((args.side_tiles, model.engine().split_tiles if args.dtype == "bf16x3" else model.engine().side_tiles), (args.big_tiles, model.engine().big_tiles)):
+    for spec, table in ((args.side_tiles, model.engine().split_tiles if args.dtype == "bf16x3" else model.engine().side_tiles), (args.big_tiles, model.engine().split_big_tiles if args.dtype == "bf16x3" else model.engine().big_tiles)):
         for item in filter(None, spec.split(",")):
             key, val = item.split("=")
             st_, op_ = key.split(".")
@@ -189,8 +189,6 @@ def main():
         model.engine().fuse_skip = False
     if args.no_fuse_xattn:
         model.engine().fuse_xattn = False
-    if args.no_attn_planes:
-        model.engine().attn_planes = False
     model.engine().cross_on_main = args.cross_on_main
     if args.interleave_capture >= 0:
         model.engine().interleave_capture = bool(args.interleave_capture)

@@ -139,10 +139,6 @@ typedef struct v2a_gemm_args {
    * v2a_split_bf16 pass.  Likewise out_dtype = V2A_BF16_SPLIT (GEGLU epilogue only): out row m = [hi | lo] planes of the N/2
    * hidden values, ldo >= N, exact erf GELU. */
   int32_t out_bf16_split;
-  /* ABI 8: columns [0, out_skip_cols) of the result go to the out_bf16 shadow only, `out` keeps what it held there (a multiple of 4; needs an
-   * fp32 `out` with a shadow; vector epilogues).  The bf16x3 mode's fused [q | k | v | gate] projection: q, k, v are consumed as hi | lo planes
-   * by v2a_attention (qkv_lo_offset), only the gate columns are read as fp32. */
-  int32_t out_skip_cols;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);
@@ -164,7 +160,7 @@ typedef struct v2a_tuning {
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t attn_one_group_from;    /* v2a_attention (bf16): launches with at least this many workgroups run one wave group per workgroup
                                    * instead of two that split the key tiles (0 = default 1536) */
-  int32_t reserved[1];            /* probe builds only */
+  int32_t reserved[1];            /* A/B bits: 128 = GEGLU epilogue with 8-byte (four-column) stores; others: probe builds only */
 } v2a_tuning;
 int v2a_set_tuning(const v2a_tuning* tuning);
 
@@ -245,10 +241,6 @@ typedef struct v2a_attn_args {
   int32_t out_split;     /* dtype V2A_BF16_SPLIT only, non-zero: out is a bf16 buffer in the V2A_BF16_SPLIT layout -- row =
                           * [hi of the H*64 outputs | lo of them], out_row_stride / out_batch_stride in bf16 elements -- i.e. the
                           * A operand of the out-projection's split GEMM, written directly */
-  int64_t qkv_lo_offset; /* ABI 8, dtype V2A_BF16_SPLIT with out_split: > 0 = q, k and v point at the bf16 HI planes of a split row and the lo
-                          * planes lie qkv_lo_offset elements further (the out_bf16_split shadow of the fused [q | k | v | gate] projection:
-                          * ld_out_bf16 = 2 * N, lo offset N); their strides are then in bf16 elements; gate stays fp32.  Same result as
-                          * the fp32 inputs those planes were made from, bit for bit, without the conversion of every K / V tile */
 } v2a_attn_args;
 
 int v2a_attention(const v2a_attn_args* args, v2a_stream_t stream);

@@ -67,12 +67,12 @@ for s in "$@"; do
     bench_nocpu) run bench_nocpu 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_shapes) run bench_shapes 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --shapes ;;
     bench8) run bench8 600 python bench.py --steps 2 --warmup 1 --clips-per-gpu 8 --no-cpu-baseline ;;
-    pmc) B="python bench.py --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs ${PMC_EXTRA:-}"
+    pmc) B="python bench.py $DTA --steps 1 --warmup 0 --cfm-steps 6 --no-cpu-baseline --no-roofline --no-graph --no-batched --no-video2roll --no-vocoder --no-parity-mode --no-configs ${PMC_EXTRA:-}"
          i=0
          for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT"; do
            i=$((i+1)); rm -rf /tmp/pmc$i
            run pmc$i 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc$i -- $B || true
-           python scripts/pmc_summary.py /tmp/pmc$i gpurun_out/pmc${i}_summary.csv
+           python scripts/pmc_summary.py /tmp/pmc$i gpurun_out/pmc${i}${PMC_TAG:-}_summary.csv
          done ;;
     pmcdw) i=0
          for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" "SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" "SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
@@ -158,6 +158,12 @@ for s in "$@"; do
           echo "--- ab [$v] ${AB_EXTRA:-}: $(grep -o '"value": [0-9.]*' gpurun_out/ab_x.log | head -1) $(grep -o '"mel_frames_per_s": [0-9.]*' gpurun_out/ab_x.log | head -1)"
         done; done ;;
     kattn) run kattn 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --tb=short -k "attention or cfg_euler" ;;
+    cutime) # chip-time accounting of one evaluation: single-stream trace (every kernel alone) + three-stream trace
+        rm -rf /tmp/tr1 /tmp/tr3
+        TAILN=2 run cut1$DTS 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr1 -- python bench.py $DTA ${CU_EXTRA:-} --single-stream --steps 1 --warmup 1 --cfm-steps 8 --no-cpu-baseline --no-roofline --no-batched --no-parity-mode --no-configs --no-video2roll --no-vocoder
+        TAILN=2 run cut3$DTS 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr3 -- python bench.py $DTA ${CU_EXTRA:-} --steps 1 --warmup 1 --cfm-steps 8 --no-cpu-baseline --no-roofline --no-batched --no-parity-mode --no-configs --no-video2roll --no-vocoder
+        python scripts/cu_time.py /tmp/tr1 /tmp/tr3 > gpurun_out/cu_time$DTS${CU_TAG:-}.txt 2>&1; cat gpurun_out/cu_time$DTS${CU_TAG:-}.txt
+        head -1 /tmp/tr1/*/*_kernel_trace.csv ;;
     *) echo "unknown step $s" ;;
   esac
 done

@@ -4,8 +4,8 @@ process: each configuration inside a hipGraph of back-to-back launches on random
 CDNA guide).  K may be a '+'-joined list of logical segments (cross-condition: 1024+1280+512).
 
 tile_hint: 0 = by shape, 1 = 64x64, 2 = 128x64, 3 = 128x128 / 8 waves / 2 stages, 4 = 64x128 / 8 waves, 5 = the 256x256 8-phase kernel on
-three passes, 6 = 128x256 / 8 waves (32-wide K stages), 7 = 64x128 / 4 waves (32-wide, 72 KB), 8 = 128x128 / 8 waves (32-wide), 9 = 64x128 / 4 waves
-/ 4 stages (32-wide).  A hint written as 6k2 adds split_k = 2 (the K range cut in slices that are summed in a fixed order).
+three passes, 6 = 128x256 / 8 waves (32-wide K stages), 7 = 128x128 / 8 waves (32-wide K stages).
+(profiles/r05_split_probe.txt was taken with two more shapes in the build: there t7 / t9 = 64x128 / 4 waves on 32-wide stages with 3 / 4 stages, and t8 = today's 7.)
 usage: python scripts/split_probe.py [--tiles 0,4,5,6,7] [--epi resid|store|geglu|gate] 1564x1024x4096 1564x1024x1024+1280+512 ...
 """
 import os
@@ -66,12 +66,8 @@ def main():
             kw = {}
         graphs, errs = {}, {}
         for t in tiles:
-            hint, sk = (t.split("k") + ["0"])[:2]
-            xkw = dict(kw)
-            if int(sk) > 1:
-                xkw.update(split_k=int(sk), workspace=L.splitk_workspace(dev))
             def call():
-                L.gemm(segs, wd, out, M=M, N=N, compute=L.BF16, a_split=True, tile_hint=int(hint), **xkw)
+                L.gemm(segs, wd, out, M=M, N=N, compute=L.BF16, a_split=True, tile_hint=int(t), **kw)
             try:
                 call()
                 torch.cuda.synchronize()

@@ -460,48 +460,6 @@ def test_attention(L, dt, B, H, Nq, Nk, kv_len, q_len, clamp):
     torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
 
 
-@pytest.mark.parametrize("B,H,N,kv_len,clamp", [(2, 2, 44, [44, 30], 50.0), (2, 16, 782, [782, 611], 50.0), (3, 3, 200, [200, 130, 65], 80.0), (1, 1, 100, [100], 0.0)])
-def test_attention_split_plane_inputs_equal_fp32_inputs(L, B, H, N, kv_len, clamp):
-    """bf16x3 self-attention fed with the hi | lo planes of [q | k | v] (qkv_lo_offset: what the QKV projection's epilogue writes as its
-    split shadow, checked here through v2a_gemm itself with out_skip_cols) against the same kernel fed with the fp32 row: the planes ARE
-    the split of those fp32 values, so the outputs are equal bit for bit."""
-    g = _g(N + H)
-    inner = H * 64
-    npad = (3 * inner + H + 15) // 16 * 16
-    K = 64
-    a = torch.randn(B * N, K, generator=g).bfloat16()
-    w = (torch.randn(npad, K, generator=g) * 0.5).bfloat16()
-    bias = 0.1 * torch.randn(npad, generator=g)
-    ad, wd = a.to(DEV), w.to(DEV)
-    # the fused [q | k | v | gate] row in fp32 (plain bf16 GEMM, fp32 out) and, from the SAME launch form, its hi | lo planes; the second
-    # launch skips the fp32 store of the q, k, v columns (they keep the poison)
-    full = torch.empty(B * N, npad, device=DEV)
-    L.gemm([(ad, K, K)], wd, full, M=B * N, N=npad, compute=L.BF16, bias=bias.to(DEV))
-    gate_only = torch.full((B * N, npad), 7.0, device=DEV)
-    planes = torch.zeros(B * N, 2 * npad, dtype=torch.bfloat16, device=DEV)
-    L.gemm([(ad, K, K)], wd, gate_only, M=B * N, N=npad, compute=L.BF16, bias=bias.to(DEV), out_bf16=planes, ld_out_bf16=2 * npad,
-           out_bf16_split=True, out_skip_cols=3 * inner)
-    assert torch.equal(gate_only[:, 3 * inner:], full[:, 3 * inner:]) and bool((gate_only[:, :3 * inner] == 7.0).all())
-    assert torch.equal(planes.cpu(), _split_planes(full.cpu()))
-    kvl = torch.tensor(kv_len, dtype=torch.int32, device=DEV)
-    kw = dict(B=B, H=H, Nq=N, Nk=N, kv_len=kvl, q_len=kvl, scale=0.125, softclamp=clamp, dtype=L.BF16_SPLIT, out_split=True)
-    o32 = torch.zeros(B * N, 2 * inner, dtype=torch.bfloat16, device=DEV)
-    opl = torch.zeros_like(o32)
-    fb = full.data_ptr()
-    L.attention(fb, fb + inner * 4, fb + 2 * inner * 4, fb + 3 * inner * 4, o32.data_ptr(),
-                strides=(npad, npad, npad, npad, 2 * inner, N * npad, N * npad, N * npad, N * npad, N * 2 * inner), **kw)
-    pb = planes.data_ptr()
-    L.attention(pb, pb + inner * 2, pb + 2 * inner * 2, gate_only.data_ptr() + 3 * inner * 4, opl.data_ptr(),
-                strides=(2 * npad, 2 * npad, 2 * npad, npad, 2 * inner, N * 2 * npad, N * 2 * npad, N * 2 * npad, N * npad, N * 2 * inner),
-                qkv_lo_offset=npad, **kw)
-    assert torch.isfinite(opl.float()).all() and float(opl.float().abs().max()) > 0
-    assert torch.equal(opl, o32)
-    with pytest.raises(L.V2AError, match="qkv_lo_offset"):
-        L.attention(pb, pb + inner * 2, pb + 2 * inner * 2, gate_only.data_ptr() + 3 * inner * 4, opl.data_ptr(),
-                    strides=(2 * npad, 2 * npad, 2 * npad, npad, 2 * inner, N * 2 * npad, N * 2 * npad, N * 2 * npad, N * npad, N * 2 * inner),
-                    qkv_lo_offset=npad + 4, **kw)
-
-
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, "split"])
 @pytest.mark.parametrize("sign", [1.0, -1.0])
 def test_attention_saturated_logits(L, dt, sign):
@@ -735,7 +693,7 @@ def _split_planes(x):
     return torch.cat([hi, lo], -1).contiguous()
 
 
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("epi", ["store", "resid_shadow", "gate_norm", "geglu"])
 @pytest.mark.parametrize("M,N,ks", [(300, 192, (256,)), (1564, 1024, (1024, 1280, 512)), (782, 1280, (1024, 1280)), (130, 2048, (512,)),
                                     (1564, 4096, (512,))])

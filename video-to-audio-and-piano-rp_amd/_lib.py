@@ -45,7 +45,7 @@ class GemmArgs(C.Structure):
         ("norm_switch_row", C.c_int32), ("norm_switch_offset", C.c_int32),
         ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64),
         ("row_ssq", C.c_void_p), ("ld_row_ssq", C.c_int64), ("row_ssq_parts", C.c_int32), ("row_norm_dim", C.c_int32),
-        ("out_bf16_split", C.c_int32), ("out_skip_cols", C.c_int32),
+        ("out_bf16_split", C.c_int32),
     ]
 
 
@@ -73,7 +73,6 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32),
         ("kv_len", C.c_void_p), ("q_len", C.c_void_p),
         ("scale", C.c_float), ("softclamp", C.c_float), ("dtype", C.c_int32), ("out_split", C.c_int32),
-        ("qkv_lo_offset", C.c_int64),
     ]
 
 
@@ -291,7 +290,7 @@ def gemm_args(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, r
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
          a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0,
          norm_gamma=None, norm_step_stride=0, norm_batch_stride=0, norm_switch_row=0, norm_switch_offset=0, norm_ssq=None,
-         row_ssq=None, row_norm_dim=0, out_bf16_split=False, a_split=False, out_split=False, out_skip_cols=0):
+         row_ssq=None, row_norm_dim=0, out_bf16_split=False, a_split=False, out_split=False):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype.
     a_split: the segments are V2A_BF16_SPLIT rows ([hi k | lo k], lda >= 2k) and w is [N][2K] = [W_hi | W_lo] (the bf16x3 mode's native
     GEMM: three MFMA products per fp32 product); out_split: GEGLU output as hi | lo planes; out_bf16_split: the shadow likewise.
@@ -337,7 +336,6 @@ def gemm_args(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, r
     g.row_ssq_parts = row_norm_dim // 32 if row_ssq is not None else 0
     g.row_norm_dim = row_norm_dim
     g.out_bf16_split = 1 if out_bf16_split else 0
-    g.out_skip_cols = out_skip_cols
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else ("a_split" if a_split else "a_bf16"),
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")
@@ -401,8 +399,7 @@ def attention(q, k, v, gate, out, **kw):
     _launch(key, flops, nbytes, lambda: lib().v2a_attention(C.byref(a), stream_ptr()))
 
 
-def attention_args(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype, out_split=False, qkv_lo_offset=0):
-    """qkv_lo_offset > 0 (dtype BF16_SPLIT): q, k, v address bf16 hi planes, the lo planes that many elements further (strides in bf16 elements)."""
+def attention_args(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_len=None, scale, softclamp, dtype, out_split=False):
     a = AttnArgs()
     a.q, a.k, a.v, a.gate, a.out = q, k, v, gate, out
     (a.q_row_stride, a.k_row_stride, a.v_row_stride, a.gate_row_stride, a.out_row_stride,
@@ -411,7 +408,6 @@ def attention_args(q, k, v, gate, out, *, strides, B, H, Nq, Nk, kv_len=None, q_
     a.kv_len, a.q_len = _p(kv_len), _p(q_len)
     a.scale, a.softclamp, a.dtype = scale, softclamp, dtype
     a.out_split = 1 if out_split else 0
-    a.qkv_lo_offset = qkv_lo_offset
     esz = 2 if dtype == BF16 else 4
     return a, "attention<%s>" % {BF16: "bf16", F32: "f32", BF16_SPLIT: "bf16x3"}[dtype], 4.0 * B * H * Nq * Nk * 64, B * H * 64 * (2 * Nq + 2 * Nk) * esz
 

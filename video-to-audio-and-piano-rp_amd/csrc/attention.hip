@@ -27,7 +27,6 @@ struct AttnParams {
   float scale, clamp;
   int32_t out_split;     // split kernel only: out is a bf16 buffer that receives hi | lo planes (lo plane H * 64 columns after hi)
   int32_t dbg;           // probe builds only
-  int64_t lo_off;        // split kernel, PLANES form: q / k / v point at bf16 hi planes, the lo planes lie lo_off elements further
 };
 
 // ------------------------------------------------------------------------------------------
@@ -390,11 +389,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
   }
 }
 
-// PLANES (round 5): q, k and v arrive as the bf16 hi | lo planes the QKV projection's epilogue wrote (v2a_gemm out_bf16_split) instead of
-// fp32 rows: the tiles go from global memory to LDS as they are -- same bytes per element, no conversion (3 VALU instructions per
-// element of every K / V tile: ~a fifth of the kernel's vector work) -- and the result is the SAME bit for bit: the epilogue's planes are
-// hi = bf16(v), lo = bf16(v - hi) of the very fp32 value this kernel would have split.
-template <int NG, int CLAMP, bool PLANES = false>
+template <int NG, int CLAMP>
 __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnParams p) {
   const int h_ = blockIdx.y;
   constexpr int TK = 64;
@@ -410,24 +405,17 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnPar
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int query = q0 + lr;
   const int kvn = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;
-  using ElemT = std::conditional_t<PLANES, bf16_t, float>;
-  const ElemT* Q = reinterpret_cast<const ElemT*>(p.q) + b * p.qbs + h * 64;
-  const ElemT* Kg = reinterpret_cast<const ElemT*>(p.k) + b * p.kbs + h * 64;
-  const ElemT* Vg = reinterpret_cast<const ElemT*>(p.v) + b * p.vbs + h * 64;
-  const int64_t lo_off = p.lo_off;
+  const float* Q = reinterpret_cast<const float*>(p.q) + b * p.qbs + h * 64;
+  const float* Kg = reinterpret_cast<const float*>(p.k) + b * p.kbs + h * 64;
+  const float* Vg = reinterpret_cast<const float*>(p.v) + b * p.vbs + h * 64;
 
   bf16x8 qh[2], ql[2];
   {
     const int qr = query < p.Nq ? query : p.Nq - 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const ElemT* qp = Q + (int64_t)qr * p.qrs + 32 * kk + 8 * g;
-      if constexpr (PLANES) {
-        qh[kk] = *reinterpret_cast<const bf16x8*>(qp);
-        ql[kk] = *reinterpret_cast<const bf16x8*>(qp + lo_off);
-      } else {
-        split8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qh[kk], ql[kk]);
-      }
+      const float* qp = Q + (int64_t)qr * p.qrs + 32 * kk + 8 * g;
+      split8(*reinterpret_cast<const f32x4*>(qp), *reinterpret_cast<const f32x4*>(qp + 4), qh[kk], ql[kk]);
     }
   }
   f32x4 o[4];
@@ -438,31 +426,24 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnPar
   const float zc = p.clamp > 0.f ? 2.0f * LOG2E * p.scale / p.clamp : p.scale * LOG2E;
   const float c2 = p.clamp * LOG2E;
 
-  // staging registers (fp32 as loaded and split when written to LDS; PLANES: the hi and lo pieces as loaded): K rows (tid>>3)+32i chunk
-  // tid&7, V likewise.  One set: written to LDS right after the barrier, re-requested at once (see attn_mfma_kernel).
+  // staging registers (fp32 as loaded; split when written to LDS): K rows (tid>>3)+32i chunk tid&7; V key pair kp = lane&31,
+  // d-chunk = 2*wave + (lane>>5).  Two sets, as in the bf16 kernel.
   struct Raw {
-    f32x4 a, b;          // fp32: elements 0..3, 4..7 of the chunk; PLANES: the 16 bytes of the hi piece, of the lo piece
+    f32x4 a, b;
   };
-  Raw kregA[2], vregA[2];
+  Raw kregA[2], vregA[2];       // one set: written to LDS right after the barrier, re-requested at once (see attn_mfma_kernel)
   const int kchunk = tid & 7, krow = tid >> 3;
   auto load_tile = [&](int j0, Raw (&kreg)[2], Raw (&vreg)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key = j0 + krow + 32 * i;
       key = key < p.Nk ? key : p.Nk - 1;
-      const ElemT* kpz = Kg + (int64_t)key * p.krs + kchunk * 8;
-      const ElemT* vpz = Vg + (int64_t)key * p.vrs + kchunk * 8;
-      if constexpr (PLANES) {
-        kreg[i].a = *reinterpret_cast<const f32x4*>(kpz);
-        kreg[i].b = *reinterpret_cast<const f32x4*>(kpz + lo_off);
-        vreg[i].a = *reinterpret_cast<const f32x4*>(vpz);
-        vreg[i].b = *reinterpret_cast<const f32x4*>(vpz + lo_off);
-      } else {
-        kreg[i].a = *reinterpret_cast<const f32x4*>(kpz);
-        kreg[i].b = *reinterpret_cast<const f32x4*>(kpz + 4);
-        vreg[i].a = *reinterpret_cast<const f32x4*>(vpz);
-        vreg[i].b = *reinterpret_cast<const f32x4*>(vpz + 4);
-      }
+      const float* kpz = Kg + (int64_t)key * p.krs + kchunk * 8;
+      kreg[i].a = *reinterpret_cast<const f32x4*>(kpz);
+      kreg[i].b = *reinterpret_cast<const f32x4*>(kpz + 4);
+      const float* vpz = Vg + (int64_t)key * p.vrs + kchunk * 8;
+      vreg[i].a = *reinterpret_cast<const f32x4*>(vpz);
+      vreg[i].b = *reinterpret_cast<const f32x4*>(vpz + 4);
     }
   };
   auto store_tile = [&](bf16_t* base, const Raw (&kreg)[2], const Raw (&vreg)[2]) {
@@ -470,20 +451,13 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnPar
     for (int i = 0; i < 2; ++i) {
       const int row = krow + 32 * i;
       const int off = row * 64 + ((kchunk ^ (row & 7)) << 3);
-      if constexpr (PLANES) {
-        *reinterpret_cast<f32x4*>(base + off) = kreg[i].a;
-        *reinterpret_cast<f32x4*>(base + K_ELEMS + off) = kreg[i].b;
-        *reinterpret_cast<f32x4*>(base + 2 * K_ELEMS + off) = vreg[i].a;
-        *reinterpret_cast<f32x4*>(base + 2 * K_ELEMS + V_ELEMS + off) = vreg[i].b;
-      } else {
-        bf16x8 hi, lo;
-        split8(kreg[i].a, kreg[i].b, hi, lo);
-        *reinterpret_cast<bf16x8*>(base + off) = hi;
-        *reinterpret_cast<bf16x8*>(base + K_ELEMS + off) = lo;
-        split8(vreg[i].a, vreg[i].b, hi, lo);
-        *reinterpret_cast<bf16x8*>(base + 2 * K_ELEMS + off) = hi;
-        *reinterpret_cast<bf16x8*>(base + 2 * K_ELEMS + V_ELEMS + off) = lo;
-      }
+      bf16x8 hi, lo;
+      split8(kreg[i].a, kreg[i].b, hi, lo);
+      *reinterpret_cast<bf16x8*>(base + off) = hi;
+      *reinterpret_cast<bf16x8*>(base + K_ELEMS + off) = lo;
+      split8(vreg[i].a, vreg[i].b, hi, lo);
+      *reinterpret_cast<bf16x8*>(base + 2 * K_ELEMS + off) = hi;
+      *reinterpret_cast<bf16x8*>(base + 2 * K_ELEMS + V_ELEMS + off) = lo;
     }
   };
   // V^T fragments by ds_read_b64_tr_b16 from the row-major planes (see attn_mfma_kernel)
@@ -922,10 +896,10 @@ int launch_attn_f32(const AttnParams& p, dim3 grid, hipStream_t s) {
   return V2A_OK;
 }
 
-template <int NG, int CLAMP, bool PLANES = false>
+template <int NG, int CLAMP>
 int launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 64) * sizeof(bf16_t);
-  auto kern = attn_mfma_split_kernel<NG, CLAMP, PLANES>;
+  auto kern = attn_mfma_split_kernel<NG, CLAMP>;
   static std::atomic<uint64_t> lds_set{0};
   if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_attention")) return rc;
   hipLaunchKernelGGL(kern, grid, dim3(256 * NG), smem, s, p);
@@ -958,30 +932,10 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
   p.out_split = a->out_split ? 1 : 0;
   p.dbg = v2a_detail::g_probe_dbg;
   V2A_REQUIRE(!a->out_split || a->dtype == V2A_BF16_SPLIT, "v2a_attention: out_split goes with dtype V2A_BF16_SPLIT");
-  V2A_REQUIRE(a->qkv_lo_offset >= 0 && (a->qkv_lo_offset == 0 || a->dtype == V2A_BF16_SPLIT), "v2a_attention: qkv_lo_offset goes with dtype V2A_BF16_SPLIT");
   hipStream_t s = (hipStream_t)stream;
   int rc = V2A_OK;
   dim3 grid((a->Nq + 63) / 64, a->H, a->B), block(64);
-  if (a->dtype == V2A_BF16_SPLIT && a->qkv_lo_offset > 0) {
-    // q, k, v as bf16 hi | lo planes (the split shadow of the QKV projection): 16-byte aligned head slices in bf16 elements, split output
-    const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15) == 0 && ((uintptr_t)a->out & 7) == 0 && a->q_row_stride % 8 == 0 &&
-                         a->k_row_stride % 8 == 0 && a->v_row_stride % 8 == 0 && a->q_batch_stride % 8 == 0 && a->k_batch_stride % 8 == 0 &&
-                         a->v_batch_stride % 8 == 0 && a->qkv_lo_offset % 8 == 0 && a->out_row_stride % 4 == 0 && a->out_batch_stride % 4 == 0;
-    V2A_REQUIRE(aligned && a->out_split && a->out_row_stride >= 2 * (int64_t)a->H * 64,
-                "v2a_attention: qkv_lo_offset (plane inputs) needs 16-byte aligned bf16 head slices, lo offset %% 8 == 0 and the split output");
-    p.lo_off = a->qkv_lo_offset;
-    const dim3 g64((a->Nq + 63) / 64, a->H, a->B);
-    const int cl = attn_clamp_mode(a->softclamp, a->Nk);
-    if (a->Nk > 128) {
-      if (cl == 2) rc = launch_attn_split<2, 2, true>(p, g64, s);
-      else if (cl == 1) rc = launch_attn_split<2, 1, true>(p, g64, s);
-      else rc = launch_attn_split<2, 0, true>(p, g64, s);
-    } else {
-      if (cl == 2) rc = launch_attn_split<1, 2, true>(p, g64, s);
-      else if (cl == 1) rc = launch_attn_split<1, 1, true>(p, g64, s);
-      else rc = launch_attn_split<1, 0, true>(p, g64, s);
-    }
-  } else if (a->dtype == V2A_BF16_SPLIT) {
+  if (a->dtype == V2A_BF16_SPLIT) {
     // fp32 tensors, split-bf16 MFMA arithmetic (bf16x3 mode); 16-byte aligned head slices and output rows, else the VALU kernel
     const bool aligned = (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->out) & 15) == 0 && a->q_row_stride % 4 == 0 &&
                          a->k_row_stride % 4 == 0 && a->v_row_stride % 4 == 0 && a->out_row_stride % 4 == 0 && a->q_batch_stride % 4 == 0 &&
@@ -990,9 +944,14 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
     const int cl = attn_clamp_mode(a->softclamp, a->Nk);
     V2A_REQUIRE(aligned || !a->out_split, "v2a_attention: out_split needs 16-byte aligned head slices");
     if (a->out_split) V2A_REQUIRE(((uintptr_t)a->out & 7) == 0 && a->out_row_stride >= 2 * (int64_t)a->H * 64, "v2a_attention: split output rows hold 2 * H * 64 bf16");
+    // two wave groups split the key tiles of a workgroup's 64 queries only while the launch is short of workgroups (< 200, or the
+    // v2a_tuning.attn_one_group_from override): one group per workgroup -- 64 KB of LDS, two workgroups per CU, no merge -- measured +1.3 % end to
+    // end at 8 clips per GPU (3328 workgroups) and +0.7 % at one clip (416 / 208), profiles/r05_bf16x3_8clips_ab.txt
+    const int one_from = v2a_detail::g_attn_one_group_from != 1536 ? v2a_detail::g_attn_one_group_from : 200;
+    const bool two_groups = a->Nk > 128 && (int64_t)g64.x * g64.y * g64.z < one_from;
     if (!aligned) {
       hipLaunchKernelGGL((attn_rowlane_kernel<float>), grid, block, 0, s, p);
-    } else if (a->Nk > 128) {
+    } else if (two_groups) {
       if (cl == 2) rc = launch_attn_split<2, 2>(p, g64, s);
       else if (cl == 1) rc = launch_attn_split<2, 1>(p, g64, s);
       else rc = launch_attn_split<2, 0>(p, g64, s);

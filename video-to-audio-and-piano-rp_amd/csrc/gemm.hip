@@ -196,7 +196,7 @@ __device__ __forceinline__ void ring_wait(int younger) {
 // BK (round 5): K extent of a ring stage, 64 or 32.  With 32 the LDS rows are 64 B -- a 1 KB DMA instruction then covers 16 rows, the
 // 16-B chunk index of a row is XOR-ed with 3 for rows 8..15 of each 16-row group (conflict-free for the lane groups of ds_read_b128:
 // every 16 lanes of a group then cover all 16 slots of a 256-B bank row) -- and a stage holds half the bytes: the split-operand 128x256
-// tile (hi + lo planes) fits three stages in 144 KB and the 64x128 one leaves room for a second workgroup on the CU.
+// tile (hi + lo planes) fits three stages in 144 KB.
 template <int EPI, typename OutT, int BM, int BN, int WGM, int WGN, int NST = 3, bool S3 = false, int BK = 64>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const GemmParams p) {
   static_assert(BK == 64 || BK == 32, "K extent of a stage");
@@ -596,7 +596,6 @@ static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
   p.ldo2 = a->ld_out_bf16;
   if (a->out_bf16) V2A_REQUIRE(a->out_dtype == V2A_F32 && a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: out_bf16 shadows an fp32 output only");
   p.out2_split = a->out_bf16 && a->out_bf16_split ? 1 : 0;
-  p.out_skip = a->out_skip_cols;
   if (p.out2_split) V2A_REQUIRE(a->ld_out_bf16 >= 2 * (int64_t)a->N, "v2a_gemm: a split shadow needs ld_out_bf16 >= 2 * N");
   p.out_split = a->out_dtype == V2A_BF16_SPLIT ? 1 : 0;
   if (p.out_split) V2A_REQUIRE(a->epilogue == V2A_EPI_GEGLU && a->ldo >= a->N, "v2a_gemm: out_dtype V2A_BF16_SPLIT goes with the GEGLU epilogue and ldo >= N");
@@ -618,10 +617,6 @@ static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
     if (a->out_bf16) ok = ok && ((uintptr_t)a->out_bf16 & 7) == 0 && a->ld_out_bf16 % 4 == 0;
     p.vec_epi = ok ? 1 : 0;
   }
-  V2A_REQUIRE(a->out_skip_cols >= 0 && a->out_skip_cols % 4 == 0 &&
-                  (a->out_skip_cols == 0 || (a->out_bf16 && a->out_dtype == V2A_F32 && p.vec_epi && a->compute_dtype == V2A_BF16 && a->a_dtype != V2A_F32)),
-              "v2a_gemm: out_skip_cols (%d) is a multiple of 4 and goes with bf16 / split operands, an fp32 output with an out_bf16 shadow and "
-              "16-byte aligned epilogue operands", a->out_skip_cols);
   p.relu = a->relu;
   // off by default: +0.7 % throughput, but the fp32 summation order of a row then depends on how many rows the call has, so a
   // clip's result would change (in the last bits) with the batch it is sampled in; v2a_set_tuning enables it
@@ -712,12 +707,12 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
   }
   if (split_in) {
     V2A_REQUIRE(p.vec_epi && !a->a_row_offset && !a->out_row_offset, "v2a_gemm: split operands need dense rows and 16-byte aligned epilogue operands");
-    V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 9, "v2a_gemm: tile_hint %d with split operands (0 = by shape, 1..9)", a->tile_hint);
+    V2A_REQUIRE(a->tile_hint >= 0 && a->tile_hint <= 7, "v2a_gemm: tile_hint %d with split operands (0 = by shape, 1..7)", a->tile_hint);
     auto nt = [&](int bm, int bn) { return (int64_t)((a->M + bm - 1) / bm) * ((a->N + bn - 1) / bn); };
     // split-operand tile shapes (hi + lo planes double a stage): 1 = 64x64 (96 KB), 2 = 128x64 (144 KB), 3 = 128x128 with 8 waves and a
     // 2-deep ring (128 KB), 4 = 64x128 with 8 waves (144 KB), 5 = the 8-phase kernel; with 32-wide K stages (round 5): 6 = 128x256 with
-    // 8 waves (wave tile 64x64; 3 stages of 48 KB), 7 = 64x128 with 4 waves (3 stages of 24 KB: two workgroups per CU), 8 = 128x128 with
-    // 8 waves (3 stages of 32 KB), 9 = 64x128 with 4 waves and 4 stages (96 KB)
+    // 8 waves (wave tile 64x64; 3 stages of 48 KB), 7 = 128x128 with 8 waves (3 stages of 32 KB).  (64x128 with four waves on 32-wide
+    // stages -- 72 KB, two workgroups per CU -- measured 15-25 % slower than shape 4 at every size: profiles/r05_split_probe.txt; not kept.)
     int cfg = a->tile_hint;
     // the phase-interleaved 256x256 kernel on three passes over the logical K (hi x hi, hi x lo, lo x hi; it re-reads A_hi and W_hi, but
     // its K loop hides the operand stream behind the MFMAs): wide outputs from 150 tiles (audio feed-forward at one clip: 76 us against
@@ -746,9 +741,7 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
       case 2: return dispatch_s3<128, 64, 2, 2, 3>(a, p, s);
       case 3: return dispatch_s3<128, 128, 2, 4, 2>(a, p, s);
       case 6: return dispatch_s3<128, 256, 2, 4, 3, 32>(a, p, s);
-      case 7: return dispatch_s3<64, 128, 2, 2, 3, 32>(a, p, s);
-      case 8: return dispatch_s3<128, 128, 2, 4, 3, 32>(a, p, s);
-      case 9: return dispatch_s3<64, 128, 2, 2, 4, 32>(a, p, s);
+      case 7: return dispatch_s3<128, 128, 2, 4, 3, 32>(a, p, s);
       default: return dispatch_s3<64, 128, 2, 4, 3>(a, p, s);
     }
   }

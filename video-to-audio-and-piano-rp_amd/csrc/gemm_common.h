@@ -57,7 +57,6 @@ struct GemmParams {
   // split (hi | lo plane) outputs of the bf16x3 mode: out2 = the shadow (lo plane N columns after hi), out = the GEGLU hidden
   // (lo plane N / 2 columns after hi)
   int32_t out2_split, out_split;
-  int32_t out_skip;         // columns [0, out_skip) are not written to `out` (their values travel in the out2 shadow only)
   // 8-phase kernel, split (hi | lo plane) operands: s3_kl = the LOGICAL K (sum of the segments' extents), K = 3 * s3_kl, and the K loop
   // walks the logical K three times: pass 0 = A_hi x W_hi, pass 1 = A_hi x W_lo, pass 2 = A_lo x W_hi -- every pass over all (up to
   // three) logical segments, whose rows are [hi k | lo k] (lda >= 2k), against weight rows [W_hi (s3_kl) | W_lo (s3_kl)].  0 = plain operands
@@ -391,6 +390,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
   }
   float rsc[TM][RPSX];
   const bool scaled = rs_row != nullptr;                           // wave-uniform
+  // GEGLU with 16-byte stores (below): needs 16-byte aligned output rows and planes
+  const bool geglu_wide = EPI == V2A_EPI_GEGLU && sizeof(OutT) == 2 && ((uintptr_t)p.out & 15) == 0 && (p.ldo & 7) == 0 && ((p.N >> 1) & 7) == 0 &&
+                          !(p.dbg & 128);       // v2a_tuning.reserved[0] bit 7: the four-column form (A/B)
   if (scaled) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -405,6 +407,52 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) tile[(lq * 4 + jj) * LD + j * 16 + lr] = acc[i][j][jj];
     // same wave wrote and reads: LDS operations of one wave complete in order, no barrier needed
+    if constexpr (EPI == V2A_EPI_GEGLU && sizeof(OutT) == 2 && (WN / 2) % 32 == 0) {
+      // bf16 / hi | lo outputs of a wave tile with >= 32 output columns: EIGHT columns per lane, so that every global store is 16 bytes (the
+      // 8-byte pieces of the four-column form below made the 128 KB of a 256x256 tile's planes a store-issue-bound tail); taken when the
+      // rows allow it (wave-uniform test), the four-column form otherwise
+      if (geglu_wide) {
+        constexpr int OC = WN / 2, LPR = OC / 8, RPI = 64 / LPR;
+        static_assert(RPI <= 16, "one slab holds 16 rows");
+        const int c8 = (lane % LPR) * 8, r0 = lane / LPR;
+        const int lc = (c8 >> 4) * 32 + (c8 & 15);            // LDS column of the first value; the gates lie 16 further
+        const int n = n_base + lc;
+        f32x4 bv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, bg[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (p.bias && n < p.N) {
+          bv[0] = *reinterpret_cast<const f32x4*>(p.bias + n);
+          bv[1] = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+          bg[0] = *reinterpret_cast<const f32x4*>(p.bias + n + 16);
+          bg[1] = *reinterpret_cast<const f32x4*>(p.bias + n + 20);
+        }
+#pragma unroll
+        for (int q = 0; q < 16 / RPI; ++q) {
+          const int r = r0 + q * RPI;
+          const int m = m_base + i * 16 + r;
+          if (m >= p.M || n >= p.N) continue;
+          const float rs = scaled ? rs_row[i * 16 + r] : 1.f;
+          bf16x8 hi, lo;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 4 * h2);
+            f32x4 g = *reinterpret_cast<const f32x4*>(tile + r * LD + lc + 16 + 4 * h2);
+            if (scaled) {          // (the same expressions as the four-column form: equal bit for bit)
+              v *= rs;
+              g *= rs;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float o32 = (v[e] + bv[h2][e]) * gelu_fast_f(g[e] + bg[h2][e]);
+              hi[4 * h2 + e] = (bf16_t)o32;
+              lo[4 * h2 + e] = (bf16_t)(o32 - (float)hi[4 * h2 + e]);
+            }
+          }
+          OutT* dst = out + (int64_t)m * p.ldo + (n_base >> 1) + c8;
+          *reinterpret_cast<bf16x8*>(dst) = hi;
+          if (p.out_split) *reinterpret_cast<bf16x8*>(dst + (p.N >> 1)) = lo;
+        }
+        continue;
+      }
+    }
     if constexpr (EPI == V2A_EPI_GEGLU) {
       constexpr int OC = WN / 2;                 // output columns of this wave
       constexpr int LPR = OC / 4;                // lanes per row
@@ -525,7 +573,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
           for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
           *reinterpret_cast<bf16x4*>(out + o_out + n) = o;
         } else {
-          if (n >= p.out_skip) *reinterpret_cast<f32x4*>(out + o_out + n) = v;
+          *reinterpret_cast<f32x4*>(out + o_out + n) = v;
           if (out2) {
             // folded RMSNorm, producer side: the shadow carries the norm's gamma (the consumer applies 1 / rms per row) and
             // the row's sum of squares is left per 32 columns (8 lanes x 4 columns: a butterfly inside the lane octet)

@@ -770,7 +770,8 @@ static int dwconv_launch(const float* x, float* out, const float* wt, const floa
     nseg = (N + SEG - 1) / SEG;
     const int64_t blocks = (int64_t)B * cb * nseg;
     // ... and only when the one-workgroup-per-CU grid fills its last round (8 clips, d = 1024: 256 blocks, 30.3 us against 39.2 us with
-    // the folded norm; d = 1280 gives 240 blocks of 17 chunks -- 50.7 us against 44.4 us -- and stays on the per-wave kernel)
+    // the folded norm; d = 1280 gives 320 blocks = 1.25 rounds, or 240 blocks of 17 chunks -- 50.7 us against 44.4 us -- and stays on the
+    // per-wave kernel; d = 512 gives 224 blocks of 7 chunks: 18.4 / 21.3 us against 19.8 / 22.0 us, round 5 -- within the noise, not taken)
     const int64_t rounds = (blocks + 255) / 256;
     if (v2a_detail::g_dwconv_stream && blocks >= 192 && blocks * 100 >= rounds * 256 * 97 && SEG <= 256) {
       const v2a_dwconv_norm none{};

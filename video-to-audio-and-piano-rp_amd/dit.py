@@ -215,6 +215,7 @@ class PackedWeights:
 # everywhere, measured only where a row exists.  bench.py --side-tiles / --big-tiles / --main-tile override entries for A/B runs.
 SHIPPED_WIDTHS = (1024, 1280, 512, 4)
 _R2, _R3 = "profiles/r02 A/B runs (DESIGN.md appendix A, `scripts/gpu_ci.sh sidetiles`)", "profiles/r03_tile_sweep.txt"
+_R5 = "profiles/r05_bf16x3_tile_sweeps.txt"
 TUNED_TILES = {
     ("bf16", 0, SHIPPED_WIDTHS): {
         # text stream co-critical with the audio stream: its 1280-wide GEMMs on 128x128 tiles with eight waves (tile 12), feed-forward in on
@@ -231,7 +232,17 @@ TUNED_TILES = {
     ("bf16", 2, SHIPPED_WIDTHS): {},
     # bf16x3, one clip: QKV of the audio / text streams (N = 3088: 91 tiles of 256x256) on the 8-phase kernel's three-segment form instead
     # of the 2-deep 128x128 split ring (90 us per launch): +1 %; everything else by shape (profiles/r03_split_gemm_probe.txt)
-    ("bf16x3", 0, SHIPPED_WIDTHS): {("a", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt"), ("t", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt")},
+    # round 5: the FRAMES stream (5 % of the flops, 17 % of the CU-time on 64x64 / 64x128 tiles: K = 512 .. 2048) on fat tiles with 32-wide K
+    # stages -- narrow GEMMs and feed-forward in on 128x256 (26 / 208 workgroups), QKV on 128x128: its chain has the slack (124 us per layer
+    # stand-alone against the audio chain's 345), the CU-time it frees goes to the audio chain: +2.7 % (profiles/r05_bf16x3_tile_sweeps.txt,
+    # sweeps 4 - 6).  The same on the text stream loses 0.6 - 3 %: its chain is as long as the audio chain's.
+    ("bf16x3", 0, SHIPPED_WIDTHS): {("a", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt"), ("t", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt"),
+                                    ("f", "qkv"): (7, _R5), ("f", "ff1"): (6, _R5), ("f", "cross"): (6, _R5), ("f", "out"): (6, _R5), ("f", "ff2"): (6, _R5)},
+    # bf16x3, launches that fill the chip several times over (8 clips per GPU): no entry.  The QKV projections on 128x256 tiles with 32-wide K
+    # stages are 4-12 % faster stand-alone than on the 8-phase kernel (228 / 280 / 80 against 240 / 290 / 91 us: 637 tiles of 256x256 are 2.49
+    # rounds, the 13th tile column holds 16 gate columns) and 1.2 % SLOWER in the sampler (3566 against 3608 mel-frames/s,
+    # profiles/r05_bf16x3_8clips_ab.txt): beside the other two queues the tail rounds are filled anyway and the 8-phase tile is the cheaper one per flop
+    ("bf16x3", 2, SHIPPED_WIDTHS): {},
 }
 
 
@@ -289,16 +300,14 @@ class DiTEngine:
         self.side_tiles = {k: v for k, v in one_clip.items() if not (k[0] == "a" and v == 14)}
         self.main_tile = 14 if any(k[0] == "a" and v == 14 for k, v in one_clip.items()) else -1
         self.big_tiles = tuned_tiles("bf16", 2, widths)
-        self.split_tiles = tuned_tiles("bf16x3", 0, widths)      # bf16x3 mode: split-operand tile shape 1..5 of v2a_gemm per (stream, op)
+        self.split_tiles = tuned_tiles("bf16x3", 0, widths)      # bf16x3 mode: split-operand tile shape 1..7 of v2a_gemm per (stream, op), up to two clips
+        self.split_big_tiles = tuned_tiles("bf16x3", 2, widths)  # ... for launches that fill the chip several times over
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
         # bf16 and bf16x3 modes, up to three clips (bf16 stand-alone: 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
         # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
         self.fuse_xattn = True
-        # bf16x3 mode: self-attention reads q, k, v as the hi | lo planes the QKV projection's epilogue writes (False: fp32 q, k, v split in
-        # the attention kernel; equal bit for bit, A/B)
-        self.attn_planes = True
         # x_at / x_af cross-condition GEMMs on the side streams (True: all three on the main stream, -2.2 %)
         self.cross_on_main = False
         # capture order: audio {cross .. self-attention}, sides {conv, norm, attention}, audio {cross-attention, feed-forward},
@@ -358,8 +367,6 @@ class DiTEngine:
             # folded RMSNorm: sums of squares per 32 columns of the row to be normed; rows padded with zeros to whole float4
             p[f"ssq_{s}"] = torch.zeros(rows, (d // 32 + 3) // 4 * 4, device=dev)
             p[f"qkv_{s}"] = e(rows, attn.n_pad, dt=self.ad)
-            if self.split:      # bf16x3: q, k, v as hi | lo planes written by the QKV projection's epilogue (the attention kernel's operands)
-                p[f"qkvp_{s}"] = e(rows, 2 * attn.n_pad, dt=cd)
             p[f"ao_{s}"] = e(rows, w2 * attn.inner, dt=cd)
             p[f"ffh_{s}"] = e(rows, w2 * ff.inner, dt=cd)
         # bf16 shadows of the fp32 residual streams (written by the producing GEMM epilogues): the
@@ -424,7 +431,7 @@ class DiTEngine:
         the tuning knobs on this object and the per-call state prepare() leaves in the plan."""
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
-                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.attn_planes, self.cross_on_main,
+                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), tuple(sorted(self.split_big_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
                 self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
@@ -521,13 +528,9 @@ class DiTEngine:
         p = self.plan
         N, rows = p["N"], nseq * p["N"]
         hn, qkv, ao = p[f"hn_{s}"], p[f"qkv_{s}"], p[f"ao_{s}"]
-        # bf16x3: the epilogue also writes the row as hi | lo bf16 planes, which the split attention kernel stages as they are (no fp32 ->
-        # plane conversion of every K / V tile; same result bit for bit); only the gate columns are then needed in fp32
-        planes = p.get(f"qkvp_{s}") if (self.split and self.attn_planes and self._fuse_rope) else None
-        pk = dict(out_bf16=planes, ld_out_bf16=2 * A.n_pad, out_skip_cols=A.gate_col) if planes is not None else {}
         if self._fuse_rope:       # RoPE of the q and k heads inside the QKV GEMM epilogue
             self._mm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad,
-                     rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **pk, **in_kw)
+                     rope_table=p["rope"], rope_cols=2 * A.inner, rope_pos_offset=0, rows_per_batch=N, **in_kw)
         else:
             self._mm([(hn, d, d)], A.w_in, qkv, M=rows, N=A.n_pad, bias=A.b_in, ldo=A.n_pad, **in_kw)
             L.rope(qkv, rows=rows, row_stride=A.n_pad, nheads=2 * A.heads, rows_per_batch=N, pos_offset=0,
@@ -536,19 +539,14 @@ class DiTEngine:
         base = qkv.data_ptr()
         lens = p["seq_len"] if p["ragged"] else None
         aw = ao.stride(-2)                      # inner, or 2 * inner in bf16x3 mode: the kernel writes hi | lo planes itself
-        if planes is not None:
-            pb, pw = planes.data_ptr(), 2 * A.n_pad
-            L.attention(pb, pb + A.inner * 2, pb + 2 * A.inner * 2, base + A.gate_col * es, ao.data_ptr(),
-                        strides=(pw, pw, pw, A.n_pad, aw, N * pw, N * pw, N * pw, N * A.n_pad, N * aw),
-                        B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens, q_len=lens if self.zero_masked_queries else None,
-                        scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=True, qkv_lo_offset=A.n_pad)
-        else:
-            L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
-                        strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, aw,
-                                 N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * aw),
-                        B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens,
-                        q_len=lens if self.zero_masked_queries else None,
-                        scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
+        # (the QKV epilogue writing q, k, v as hi | lo planes for the split attention kernel -- no conversion of the K / V tiles there -- is bit-equal
+        # and 1.5-2 % SLOWER end to end: profiles/r05_attn_planes_ab.txt; not kept)
+        L.attention(base, base + A.inner * es, base + 2 * A.inner * es, base + A.gate_col * es, ao.data_ptr(),
+                    strides=(A.n_pad, A.n_pad, A.n_pad, A.n_pad, aw,
+                             N * A.n_pad, N * A.n_pad, N * A.n_pad, N * A.n_pad, N * aw),
+                    B=nseq, H=A.heads, Nq=N, Nk=N, kv_len=lens,
+                    q_len=lens if self.zero_masked_queries else None,
+                    scale=self.cfg.dim_head ** -0.5, softclamp=self.softclamp, dtype=self.adc, out_split=self.split)
         self._mm([(ao, A.inner, A.inner)], A.w_out, x, M=rows, N=d, resid=x, ldo=d, ldr=d, **out_kw)
 
     def _ff(self, Fw: _FF, x, s, nseq, d, out_kw, in_kw={}):
@@ -568,8 +566,8 @@ class DiTEngine:
         two clips: M <= 3128 rows); with more rows every kernel fills all CUs and the library's stand-alone choice is faster
         (8 clips: text feed-forward 325 us on the 256x256 kernel against 556 us on forced 128x256 tiles).  `side_tiles` maps
         (stream, op) to a tile configuration of v2a_tuning.gemm_force_tile; missing entries take `side_tile`."""
-        if self.split:                      # split-operand GEMMs have their own four tile shapes (v2a_gemm): 0 = by shape
-            return self.split_tiles.get((stream, op), 0)
+        if self.split:                      # split-operand GEMMs have their own tile shapes (v2a_gemm): 0 = by shape
+            return (self.split_big_tiles if self._regime() == 2 else self.split_tiles).get((stream, op), 0)
         if self.side_tile < 0:
             return 0
         r = self._regime()
@@ -581,7 +579,7 @@ class DiTEngine:
 
     def _main_hint(self, op=None):
         if self.split:
-            t = self.split_tiles.get(("a", op), 0)
+            t = (self.split_big_tiles if self._regime() == 2 else self.split_tiles).get(("a", op), 0)
             return dict(tile_hint=t) if t else {}
         r = self._regime()
         if r == 2:
