@@ -62,12 +62,13 @@ _T0 = time.perf_counter()
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PMC_FILES = ("r04_pmc1_summary.csv", "r04_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the committed rocprofv3 --pmc runs
-ROCPROF_STATS = "r04_kernel_stats_singlestream.csv"              # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
-ROCPROF_STATS_MULTI = "r04_kernel_stats_multistream.csv"         # ... of the production configuration (three streams)
-ROCPROF_STATS_8CLIPS = "r04_kernel_stats_8clips.csv"             # ... of `bench.py --clips-per-gpu 8`
-ROCPROF_STATS_8CLIPS_ALONE = "r04_kernel_stats_8clips_singlestream.csv"   # ... of `bench.py --clips-per-gpu 8 --single-stream`: every kernel alone on the chip
-
+# committed rocprofv3 summaries of THIS build in the headline mode (bf16x3), produced by scripts/gpu_ci.sh (profiles/README.md):
+PMC_FILES = ("r05_pmc1_summary.csv", "r05_pmc2_summary.csv")    # FETCH_SIZE pass, WRITE_SIZE pass of the rocprofv3 --pmc runs (one clip, three streams)
+PMC_FILES_8CLIPS = ("r05_pmc1_8clips_summary.csv", "r05_pmc2_8clips_summary.csv")   # ... of `--clips-per-gpu 8`
+ROCPROF_STATS = "r05_kernel_stats_bf16x3_singlestream.csv"       # rocprofv3 --kernel-trace --stats of `bench.py --single-stream`
+ROCPROF_STATS_MULTI = "r05_kernel_stats_bf16x3_multistream.csv"  # ... of the production configuration (three streams)
+ROCPROF_STATS_8CLIPS = "r05_kernel_stats_bf16x3_8clips.csv"      # ... of `bench.py --clips-per-gpu 8`
+ROCPROF_STATS_8CLIPS_ALONE = "r05_kernel_stats_bf16x3_8clips_singlestream.csv"   # ... of `bench.py --clips-per-gpu 8 --single-stream`: every kernel alone on the chip
 
 def main():
     ap = argparse.ArgumentParser()
@@ -336,7 +337,7 @@ def main():
                 r8 = roofline_leg(model, L, args)
                 hbm["clips_8"] = r8.pop("hbm")
                 res["batched"]["roofline"] = {k: r8[k] for k in ("kernel", "scope", "achieved", "frac", "avg_launch_us", "launches_per_eval", "all_gemm_tflops",
-                                                                   "all_gemm_frac", "eval_kernel_ms", "kernels", "frac_mfma_issued", "all_gemm_frac_mfma_issued") if k in r8}
+                                                                   "all_gemm_frac", "eval_kernel_ms", "kernels", "frac_mfma_issued", "all_gemm_frac_mfma_issued", "traffic") if k in r8}
             log("batched leg done")
         if not args.no_roofline:
             one_step()                                     # restore this run's plan (and its graph) after the batched leg
@@ -480,7 +481,19 @@ def summary_fields(res):
                     rp = rocprof_avg(k, row["tflops"] * 1e12 * row["avg_us"] * 1e-6, PEAK_BF16_TFLOPS, ROCPROF_STATS_8CLIPS_ALONE)
                     if rp:
                         row["rocprof"] = {"avg_us": rp["avg_us"], "frac": rp["frac"]}
+            # HBM / fabric traffic of the 8-clip GEGLU and QKV classes from the committed PMC passes of `--clips-per-gpu 8` (FETCH_SIZE x 2 + WRITE_SIZE per
+            # launch) against the algorithmic bytes of the launch: co-running chip-filling kernels do not re-fetch more
+            tr8 = {}
+            for k, row in r8["kernels"].items():
+                if k.startswith("gemm<bf16") and "alg_MB_per_launch" in row and k.split(",")[2] in ("geglu", "store"):
+                    t = pmc_traffic(k, row["alg_MB_per_launch"] * 1e6, PMC_FILES_8CLIPS)
+                    if t:
+                        row["traffic"] = {"MB_per_launch": round(t["bytes_per_launch"] / 1e6, 2), "ratio": t["ratio"]}
+                        cls = "qkv_store" if k.split(",")[2] == "store" else "geglu"
+                        if cls not in tr8 or row["share"] > tr8[cls][1]:
+                            tr8[cls] = (t["ratio"], row["share"])
             if roof is not None:
+                roof.update({"clips8_traffic_ratio_" + c: v[0] for c, v in tr8.items()})
                 roof.update({"clips8_all_gemm_frac": r8["all_gemm_frac"], "clips8_mel_frames_per_s": b["mel_frames_per_s"], "clips8_mode": head,
                              **{"clips8_frac_" + k: v[0] for k, v in fr.items()}})
                 if "all_gemm_frac_mfma_issued" in r8:
@@ -769,6 +782,8 @@ def roofline_leg(model, L, args, production=False):
                 row["tflops"] = round(a["flops"] / (3.0 if split_k else 1.0) / (a["ms"] * 1e-3) / 1e12, 2)
                 if split_k:
                     row["tflops_mfma_issued"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2)
+                if k.startswith("gemm"):
+                    row["alg_MB_per_launch"] = round(a["bytes"] / a["launches"] / 1e6, 2)
             else:
                 row["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
             table[k] = row
@@ -791,7 +806,8 @@ def roofline_leg(model, L, args, production=False):
         dom_k, alg = pk, pdom["bytes"] / pdom["launches"]
     else:
         out.update(alone)
-    out["traffic"] = pmc_traffic(dom_k, alg)
+    # the committed PMC passes were taken in the configuration of the same name: three streams at one clip, or 8 clips per GPU
+    out["traffic"] = pmc_traffic(dom_k, alg, PMC_FILES_8CLIPS if model.engine().plan["B"] >= 8 else PMC_FILES)
     out["hbm"] = hbm
     return out
 
@@ -969,7 +985,7 @@ def rocprof_hbm(key, bytes_per_launch, stats_file):
         return None
 
 
-def pmc_traffic(kernel_key, algorithmic_bytes=None):
+def pmc_traffic(kernel_key, algorithmic_bytes=None, files=None):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/ files named in PMC_FILES; FETCH_SIZE and WRITE_SIZE collected in separate passes, KB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC collection cannot run inside
@@ -978,13 +994,14 @@ def pmc_traffic(kernel_key, algorithmic_bytes=None):
         def pick(fn):
             rs = _kernel_rows(fn, kernel_key, "kernel")
             return max(rs, key=lambda r: int(r["dispatches"])) if rs else None
-        f, w = pick(PMC_FILES[0]), pick(PMC_FILES[1])
+        files = files or PMC_FILES
+        f, w = pick(files[0]), pick(files[1])
         if f is None or w is None:
             return None
         fetch = float(f["FETCH_SIZE"]) * 1024 * 2 / int(f["dispatches"])
         write = float(w["WRITE_SIZE"]) * 1024 / int(w["dispatches"])
         out = {"bytes_per_launch": round(fetch + write), "fetch_bytes": round(fetch), "write_bytes": round(write),
-               "source": "profiles/%s + %s (rocprofv3 --pmc, separate passes; FETCH_SIZE x2)" % PMC_FILES}
+               "source": "profiles/%s + %s (rocprofv3 --pmc, separate passes; FETCH_SIZE x2)" % tuple(files)}
         if algorithmic_bytes:
             # operands once (A, W), the residual row read, the fp32 result and its bf16 shadow written: what one launch must move
             out["algorithmic_bytes"] = round(algorithmic_bytes)

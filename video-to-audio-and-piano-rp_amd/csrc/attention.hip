@@ -389,20 +389,25 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
   }
 }
 
-template <int NG, int CLAMP>
-__global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnParams p) {
+// QG (round 5): 2 = TWO groups of four waves share the K / V tiles of one ring -- 128 queries per workgroup, every thread converts and
+// stages half as many K / V elements per tile and the tiles are fetched once per 128 queries instead of once per 64 (with NG = 1 only).
+template <int NG, int CLAMP, int QG = 1>
+__global__ __launch_bounds__(256 * NG * QG) void attn_mfma_split_kernel(const AttnParams p) {
+  static_assert(QG == 1 || (QG == 2 && NG == 1), "query groups come with one key group");
   const int h_ = blockIdx.y;
   constexpr int TK = 64;
   constexpr int K_ELEMS = TK * 64, V_ELEMS = TK * 64;     // all four planes row-major [key][64], swizzled like the bf16 kernel's
   constexpr int STAGE = 2 * (K_ELEMS + V_ELEMS);          // Kh | Kl | Vh | Vl
   constexpr int RING = 2 * STAGE;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_dyn[];
-  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int hi_grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int grp = QG == 2 ? 0 : hi_grp;                   // key group (NG = 2) ...
+  const int qgrp = QG == 2 ? hi_grp : 0;                  // ... or query group (QG = 2)
   bf16_t* lds = lds_dyn + grp * RING;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int h = h_, b = blockIdx.z;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = blockIdx.x * (64 * QG) + qgrp * 64 + wave * 16;
   const int query = q0 + lr;
   const int kvn = p.kv_len ? min(p.kv_len[b], p.Nk) : p.Nk;
   const float* Q = reinterpret_cast<const float*>(p.q) + b * p.qbs + h * 64;
@@ -431,11 +436,13 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnPar
   struct Raw {
     f32x4 a, b;
   };
-  Raw kregA[2], vregA[2];       // one set: written to LDS right after the barrier, re-requested at once (see attn_mfma_kernel)
-  const int kchunk = tid & 7, krow = tid >> 3;
-  auto load_tile = [&](int j0, Raw (&kreg)[2], Raw (&vreg)[2]) {
+  constexpr int NR = 2 / QG;    // row passes per thread and tile: the 64 key rows over 256 (QG = 1) or 512 (QG = 2) staging threads
+  Raw kregA[NR], vregA[NR];     // one set: written to LDS right after the barrier, re-requested at once (see attn_mfma_kernel)
+  const int stid = QG == 2 ? (int)threadIdx.x : tid;
+  const int kchunk = stid & 7, krow = stid >> 3;
+  auto load_tile = [&](int j0, Raw (&kreg)[NR], Raw (&vreg)[NR]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NR; ++i) {
       int key = j0 + krow + 32 * i;
       key = key < p.Nk ? key : p.Nk - 1;
       const float* kpz = Kg + (int64_t)key * p.krs + kchunk * 8;
@@ -446,9 +453,9 @@ __global__ __launch_bounds__(256 * NG) void attn_mfma_split_kernel(const AttnPar
       vreg[i].b = *reinterpret_cast<const f32x4*>(vpz + 4);
     }
   };
-  auto store_tile = [&](bf16_t* base, const Raw (&kreg)[2], const Raw (&vreg)[2]) {
+  auto store_tile = [&](bf16_t* base, const Raw (&kreg)[NR], const Raw (&vreg)[NR]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int row = krow + 32 * i;
       const int off = row * 64 + ((kchunk ^ (row & 7)) << 3);
       bf16x8 hi, lo;
@@ -896,13 +903,14 @@ int launch_attn_f32(const AttnParams& p, dim3 grid, hipStream_t s) {
   return V2A_OK;
 }
 
-template <int NG, int CLAMP>
+template <int NG, int CLAMP, int QG = 1>
 int launch_attn_split(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr size_t smem = (size_t)NG * 2 * 2 * (64 * 64 + 64 * 64) * sizeof(bf16_t);
-  auto kern = attn_mfma_split_kernel<NG, CLAMP>;
+  auto kern = attn_mfma_split_kernel<NG, CLAMP, QG>;
   static std::atomic<uint64_t> lds_set{0};
   if (int rc = v2a_enable_lds(reinterpret_cast<const void*>(kern), smem, lds_set, "v2a_attention")) return rc;
-  hipLaunchKernelGGL(kern, grid, dim3(256 * NG), smem, s, p);
+  grid.x = (grid.x + QG - 1) / QG;                 // 64 * QG queries per workgroup
+  hipLaunchKernelGGL(kern, grid, dim3(256 * NG * QG), smem, s, p);
   return V2A_OK;
 }
 
@@ -955,6 +963,11 @@ extern "C" int v2a_attention(const v2a_attn_args* a, v2a_stream_t stream) {
       if (cl == 2) rc = launch_attn_split<2, 2>(p, g64, s);
       else if (cl == 1) rc = launch_attn_split<2, 1>(p, g64, s);
       else rc = launch_attn_split<2, 0>(p, g64, s);
+    } else if (a->Nq > 64 && a->Nk > 128 && !(v2a_detail::g_probe_dbg & 256)) {
+      // one key group, two query groups per workgroup (128 queries share every K / V tile); v2a_tuning.reserved[0] bit 8: the 64-query form (A/B)
+      if (cl == 2) rc = launch_attn_split<1, 2, 2>(p, g64, s);
+      else if (cl == 1) rc = launch_attn_split<1, 1, 2>(p, g64, s);
+      else rc = launch_attn_split<1, 0, 2>(p, g64, s);
     } else {
       if (cl == 2) rc = launch_attn_split<1, 2>(p, g64, s);
       else if (cl == 1) rc = launch_attn_split<1, 1>(p, g64, s);
