@@ -36,6 +36,30 @@ def short(n):
     return (m.group(1) if m else n)[:60]
 
 
+def dyn_lds(name):
+    """Dynamic LDS of this library's kernels by instantiation (the trace's LDS_Block_Size holds the static part only)."""
+    n = re.sub(r"\(anonymous namespace\)::|void ", "", name)
+    if "gemm_bf16_8ph_kernel" in n:
+        return 2 * 4 * 128 * 128 + 1024
+    m = re.search(r"gemm_bf16_dma_kernel<(\d+), [^,]+, (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+)>", n)
+    if not m:
+        m2 = re.search(r"gemm_bf16_dma_kernelILi(\d+)E(?:f|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", n)
+        if m2:
+            g = m2.groups()
+            m = type("M", (), {"groups": lambda self: (g[0], g[1], g[2], g[3], g[4], g[5], "true" if g[6] == "1" else "false", g[7])})()
+    if m:
+        _, bm, bn, _, _, nst, s3, bk = m.groups()
+        return int(nst) * (int(bm) + int(bn)) * int(bk) * 2 * (2 if s3 == "true" else 1) + int(bm) * 4 + 16
+    m = re.search(r"attn_mfma_split_kernel<(\d+)", n)
+    if m:
+        return int(m.group(1)) * 2 * 2 * (64 * 64 + 64 * 64) * 2
+    if "qproj_xattn_kernel" in n:
+        return 100 * 1024 if "true" in n else 52 * 1024
+    if "dwconv_stream_kernel" in n:
+        return 135 * 1024
+    return 0
+
+
 ev = one_eval(rows_of(sys.argv[1]))
 agg = collections.OrderedDict()
 tot_t = tot_cu = 0.0
@@ -44,7 +68,7 @@ for r in ev:
     grid = max(1, num(r, "Grid_Size", "Grid_Size_X")) * max(1, num(r, "Grid_Size_Y")) * max(1, num(r, "Grid_Size_Z"))
     wg = max(1, num(r, "Workgroup_Size", "Workgroup_Size_X")) * max(1, num(r, "Workgroup_Size_Y")) * max(1, num(r, "Workgroup_Size_Z"))
     nwg = max(1, grid // wg)
-    lds = num(r, "LDS_Block_Size", "LDS_Block_Size_v")
+    lds = num(r, "LDS_Block_Size", "LDS_Block_Size_v") + dyn_lds(r["Kernel_Name"])
     vg = num(r, "VGPR_Count") + num(r, "Accum_VGPR_Count")
     waves = (wg + 63) // 64
     per_simd = max(1, min(8, 512 // max(8, (vg + 7) // 8 * 8)))

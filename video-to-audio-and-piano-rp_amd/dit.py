@@ -921,6 +921,9 @@ class DiTEngine:
                         self._side_block(nxt, "f", fbuf[0], fbuf[1], Bt, Df, (part,))
             if nctx > 0:
                 self._audio_cross_attention(i, ly, x, nctx, cons2, fold2, lens)
+            # (holding the side streams' feed-forward launches back until here -- this out-projection's 208 small workgroups take 118-134 us
+            # instead of 13.6 behind the 280 + 208 fat workgroups of those launches -- only moves the bubble: the text feed-forward then takes
+            # 265 us and the audio queue waits for the text chain, -3.4 %: profiles/r05_hold_side_ff_ab.txt)
             if not fold2:
                 self._norm_ada(x, p["hn_a"], rows, D, i, 2)
             # the bf16 copy of this layer's output: into the wide buffer of the next layer's skip when that layer is fused
