@@ -302,12 +302,8 @@ int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t T, int32_t
                    v2a_stream_t stream);
 int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C,
                   int64_t pred_batch_stride, int32_t row_off, float cfg_strength,
-                  const float* dt, int32_t* step, const double* apg,
-                  float keep_parallel_frac,
-                  int32_t* arrival /* ABI 8: NULL, or one zeroed device int private to the stream: the launch then ALSO advances the step
-                                      counter (step[0] += 1 by the last of its blocks to have used it; the count re-arms itself) -- the
-                                      v2a_step_advance launch behind every evaluation is not needed */,
-                  v2a_stream_t stream);
+                  const float* dt, const int32_t* step, const double* apg,
+                  float keep_parallel_frac, v2a_stream_t stream);
 /* y[r][0:d] = hi, y[r][d:2d] = lo of x[r][0:d] (V2A_BF16_SPLIT layout above), rows x d fp32 in, row strides in elements,
  * d % 4 == 0: the split operand copy of an fp32 buffer (residual streams, attention outputs, GEGLU hidden) for the
  * three-segment bf16 GEMMs of the bf16x3 mode */
@@ -315,7 +311,7 @@ int v2a_split_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t ro
 /* y[i] = bf16(x[i]), n % 4 == 0: bf16 operand copy of an fp32 stream that no GEMM epilogue produced
  * (the embed output x3:2027 feeding the first cross-condition GEMM) */
 int v2a_cast_bf16(const float* x, void* y, int64_t n, v2a_stream_t stream);
-/* step[0] += 1 as a launch of its own (callers that do not pass `arrival` to v2a_cfg_euler) */
+/* step[0] += 1 (own launch: every block of the step has read step[0] before it runs) */
 int v2a_step_advance(int32_t* step, v2a_stream_t stream);
 
 /* =======================================================================================

@@ -4,7 +4,7 @@ import csv, glob, re, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adv = [i for i, r in enumerate(rows) if "cfg_euler" in r["Kernel_Name"]]      # the last kernel of an evaluation
+adv = [i for i, r in enumerate(rows) if "step_advance" in r["Kernel_Name"]]
 a, b = adv[-4], adv[-3]
 ev = rows[a + 1:b + 1]
 t0, t1 = int(ev[0]["Start_Timestamp"]), int(ev[-1]["End_Timestamp"])

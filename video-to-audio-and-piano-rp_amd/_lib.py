@@ -126,7 +126,7 @@ def _declare(lib):
     lib.v2a_fill_registers.argtypes = [vp, i64, vp, i32, i32, i32, vp]
     lib.v2a_time_cond.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp]
     lib.v2a_apg_reduce.argtypes = [vp, vp, i32, i32, i32, i64, i32, vp, vp]
-    lib.v2a_cfg_euler.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, f32, vp, vp]
+    lib.v2a_cfg_euler.argtypes = [vp, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, f32, vp]
     lib.v2a_step_advance.argtypes = [vp, vp]
     lib.v2a_cast_bf16.argtypes = [vp, vp, i64, vp]
     lib.v2a_split_bf16.argtypes = [vp, i64, vp, i64, i64, i32, vp]
@@ -466,11 +466,10 @@ def apg_reduce(pred, apg, *, B, T, C_, pred_batch_stride, row_off, valid_rows=No
     check(lib().v2a_apg_reduce(pred.data_ptr(), apg.data_ptr(), B, T, C_, pred_batch_stride, row_off, _p(valid_rows), stream_ptr()))
 
 
-def cfg_euler(y, pred, *, B, T, C_, pred_batch_stride, row_off, cfg_strength, dt, step=None, apg=None, keep=0.0, arrival=None):
-    """arrival: one zeroed device int -- the launch then also advances `step` (no v2a_step_advance launch needed)."""
+def cfg_euler(y, pred, *, B, T, C_, pred_batch_stride, row_off, cfg_strength, dt, step=None, apg=None, keep=0.0):
     _launch("cfg_euler", 0.0, 16.0 * B * T * C_,
             lambda: lib().v2a_cfg_euler(y.data_ptr(), pred.data_ptr(), B, T, C_, pred_batch_stride, row_off,
-                                        float(cfg_strength), dt.data_ptr(), _p(step), _p(apg), float(keep), _p(arrival), stream_ptr()))
+                                        float(cfg_strength), dt.data_ptr(), _p(step), _p(apg), float(keep), stream_ptr()))
 
 
 def step_advance(step):

@@ -592,59 +592,40 @@ __global__ __launch_bounds__(256) void time_cond_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------
 // CFG + Euler.  Algorithmic traffic per element: read pc, pn, y + write y = 16 B.
 // ------------------------------------------------------------------------------------------
-// `arrival` (round 5): the step counter is advanced by this launch itself -- every block counts in once all its threads have used
-// step[0], and the last one to arrive increments it and re-arms the count -- instead of by a one-thread kernel behind it.
-// Two float4 per thread, all six loads requested before the first use: 12 MB at 8 clips is a latency-bound launch.
+// (Round 5 measured the step counter advanced by this launch itself -- every block counts in through a device atomic once it has used
+// step[0], the last one increments -- instead of by the one-thread launch behind it: 750 same-address atomics cost the launch ~3 us
+// (8.3 against 5.2 us at 8 clips, profiles/r05_kernel_stats_bf16x3_8clips_singlestream.csv), as much as the launch they replace.  Not kept.)
 __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ y, const float* __restrict__ pred, int B,
                                                         int T, int C, int64_t pbs, int row_off, float s,
-                                                        const float* __restrict__ dt, int32_t* step,
-                                                        const double* apg, float keep, int32_t* arrival) {
+                                                        const float* __restrict__ dt, const int32_t* step,
+                                                        const double* apg, float keep) {
+  const int64_t idx4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t per_b = (int64_t)T * C;
   const int64_t total4 = (int64_t)B * per_b / 4;
+  if (idx4 >= total4) return;
+  const int64_t e = idx4 * 4;
+  const int64_t b = e / per_b, r = e % per_b;
   const float h = dt[step ? step[0] : 0];
-  const int64_t i0 = ((int64_t)blockIdx.x * 2) * blockDim.x + threadIdx.x;
-  f32x4 pc[2], pn[2], yv[2];
-  int64_t e[2], bb[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int64_t idx4 = i0 + u * blockDim.x;
-    e[u] = (idx4 < total4 ? idx4 : 0) * 4;
-    bb[u] = e[u] / per_b;
-    const int64_t r = e[u] % per_b;
-    pc[u] = *reinterpret_cast<const f32x4*>(pred + bb[u] * pbs + (int64_t)row_off * C + r);
-    pn[u] = *reinterpret_cast<const f32x4*>(pred + (bb[u] + B) * pbs + (int64_t)row_off * C + r);
-    yv[u] = *reinterpret_cast<const f32x4*>(y + e[u]);
+  const f32x4 pc = *reinterpret_cast<const f32x4*>(pred + b * pbs + (int64_t)row_off * C + r);
+  const f32x4 pn = *reinterpret_cast<const f32x4*>(pred + (b + B) * pbs + (int64_t)row_off * C + r);
+  f32x4 yv = *reinterpret_cast<const f32x4*>(y + e);
+  float coef = 0.f;
+  if (apg) {
+    // parallel = (<upd, pred> / <pred, pred>) * pred  (unit = pred / max(|pred|, 1e-12))
+    const double dot = apg[2 * b], nn = apg[2 * b + 1];
+    const double nrm = sqrt(nn) > 1e-12 ? sqrt(nn) : 1e-12;
+    coef = (float)(dot / (nrm * nrm));
   }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    float coef = 0.f;
+  for (int j = 0; j < 4; ++j) {
+    float upd = pc[j] - pn[j];
     if (apg) {
-      // parallel = (<upd, pred> / <pred, pred>) * pred  (unit = pred / max(|pred|, 1e-12))
-      const double dot = apg[2 * bb[u]], nn = apg[2 * bb[u] + 1];
-      const double nrm = sqrt(nn) > 1e-12 ? sqrt(nn) : 1e-12;
-      coef = (float)(dot / (nrm * nrm));
+      const float par = coef * pc[j];
+      upd = (upd - par) + par * keep;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float upd = pc[u][j] - pn[u][j];
-      if (apg) {
-        const float par = coef * pc[u][j];
-        upd = (upd - par) + par * keep;
-      }
-      yv[u][j] += h * (pc[u][j] + upd * s);
-    }
-    if (i0 + u * blockDim.x < total4) *reinterpret_cast<f32x4*>(y + e[u]) = yv[u];
+    yv[j] += h * (pc[j] + upd * s);
   }
-  if (arrival) {
-    __syncthreads();                 // every thread of the block has used step[0] (h feeds the stores above)
-    if (threadIdx.x == 0) {
-      const int a = __hip_atomic_fetch_add(arrival, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a == (int)gridDim.x - 1) {   // all other blocks have counted in, i.e. read step[0]
-        step[0] += 1;
-        __hip_atomic_store(arrival, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
+  *reinterpret_cast<f32x4*>(y + e) = yv;
 }
 
 __global__ __launch_bounds__(256) void apg_reduce_kernel(const float* __restrict__ pred, double* __restrict__ apg, int B,
@@ -920,14 +901,13 @@ extern "C" int v2a_apg_reduce(const float* pred, double* apg, int32_t B, int32_t
 }
 
 extern "C" int v2a_cfg_euler(float* y, const float* pred, int32_t B, int32_t T, int32_t C, int64_t pbs, int32_t row_off,
-                             float cfg_strength, const float* dt, int32_t* step, const double* apg, float keep,
-                             int32_t* arrival, v2a_stream_t stream) {
+                             float cfg_strength, const float* dt, const int32_t* step, const double* apg, float keep,
+                             v2a_stream_t stream) {
   V2A_REQUIRE(y && pred && dt, "v2a_cfg_euler: null pointer");
-  V2A_REQUIRE(!arrival || step, "v2a_cfg_euler: arrival (advance the step counter) needs step");
   V2A_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && pbs % 4 == 0, "v2a_cfg_euler: B=%d T=%d C=%d", B, T, C);
   const int64_t total4 = (int64_t)B * T * C / 4;
-  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((total4 + 511) / 512)), dim3(256), 0, (hipStream_t)stream, y, pred,
-                     B, T, C, pbs, row_off, cfg_strength, dt, step, apg, keep, arrival);
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, pred,
+                     B, T, C, pbs, row_off, cfg_strength, dt, step, apg, keep);
   return v2a_check_launch("v2a_cfg_euler");
 }
 

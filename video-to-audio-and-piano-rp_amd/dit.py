@@ -397,9 +397,7 @@ class DiTEngine:
         p["gate_tab"] = e(S, c.depth, 3, D)
         p["t_pts"] = e(S)
         p["dt"] = e(S)
-        # [step counter | arrival count of v2a_cfg_euler, which advances the counter itself]
-        p["step2"] = torch.zeros(2, dtype=torch.int32, device=dev)
-        p["step"], p["arrival"] = p["step2"][:1], p["step2"][1:]
+        p["step"] = torch.zeros(1, dtype=torch.int32, device=dev)
         p["apg"] = torch.zeros(2 * B, dtype=torch.float64, device=dev)
         # latent frames of the CALL (<= T when the plan is padded to a shape bucket): the APG sums of x3:162-173 run over the call's own
         # (b, n, C) tensor, not over padding rows.  A device int -- a captured graph bakes scalar arguments, and one graph serves a bucket
@@ -969,5 +967,5 @@ class DiTEngine:
         if remove_parallel_component:
             L.apg_reduce(p["pred"], p["apg"], valid_rows=p["valid_T"], **kw)
             apg = p["apg"]
-        # (the launch also advances the step counter: its last block to arrive increments it)
-        L.cfg_euler(y, p["pred"], cfg_strength=cfg_strength, dt=p["dt"], step=p["step"], apg=apg, keep=keep_parallel_frac, arrival=p["arrival"], **kw)
+        L.cfg_euler(y, p["pred"], cfg_strength=cfg_strength, dt=p["dt"], step=p["step"], apg=apg, keep=keep_parallel_frac, **kw)
+        L.step_advance(p["step"])
