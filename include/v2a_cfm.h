@@ -160,7 +160,7 @@ typedef struct v2a_tuning {
                                    * per-shape gm x gn rectangle grid that minimises operand re-fetch across the 8 L2s */
   int32_t attn_one_group_from;    /* v2a_attention (bf16): launches with at least this many workgroups run one wave group per workgroup
                                    * instead of two that split the key tiles (0 = default 1536) */
-  int32_t reserved[1];            /* A/B bits: 128 = GEGLU epilogue with 8-byte (four-column) stores; others: probe builds only */
+  int32_t reserved[1];            /* A/B bits: 128 = GEGLU epilogue with 8-byte (four-column) stores, 256 = split attention with 64 queries per workgroup, 512 = 8-phase kernel multiplies padding row bands too; others: probe builds only */
 } v2a_tuning;
 int v2a_set_tuning(const v2a_tuning* tuning);
 

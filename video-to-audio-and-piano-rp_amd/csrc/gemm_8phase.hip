@@ -148,8 +148,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
       bf[j][1] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + ch1);
     }
   };
+  // Row bands of the tile that lie wholly behind the last row of the problem are not multiplied (round 5): M = 1564 leaves the seventh
+  // 256-row tile band of a one-clip launch with 28 valid rows -- three of its four 64-row bands (six of eight quadrant phases per wave pair) would
+  // multiply padding.  The phases keep their barriers, fragment reads and DMAs (the counted vmcnt chain does not change); a skipped quadrant costs no
+  // MFMA issue, so such a workgroup's K loop runs at the pace of its operand stream and frees its CU early.  Wave-uniform: wr comes from readfirstlane.
+  // (The 32-column bands behind the last column -- N = 3088 leaves the 13th tile column 16 columns wide -- skipped the same way: +-0 at 1 and 8 clips,
+  // profiles/r05_bf16x3_8clips_ab.txt item 6; not kept.)
+  const int rows_valid = (p.dbg & 512) ? 256 : p.M - m0;       // v2a_tuning.reserved[0] bit 9: multiply every band (A/B)
+  const bool need0 = wr * 128 < rows_valid, need1 = wr * 128 + 64 < rows_valid;
   auto quadrant = [&](auto sa_c, auto sb_c, const bf16x8 (&bf)[2][2]) {
     constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value;
+    if (!(SA == 0 ? need0 : need1)) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)

@@ -401,6 +401,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    if (m_base + i * 16 >= M) continue;          // a slab wholly behind the last row (wave-uniform): nothing to stage or store
     // one 16-row slab of the wave tile at a time: the staging area of a workgroup is a few KB of one ring stage
 #pragma unroll
     for (int j = 0; j < TN; ++j)
