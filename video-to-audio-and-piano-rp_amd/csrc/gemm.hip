@@ -728,6 +728,9 @@ extern "C" int v2a_gemm(const v2a_gemm_args* a, v2a_stream_t stream) {
 #endif
       return v2a_detail::launch_gemm_8phase(q, a->epilogue, a->out_dtype == V2A_BF16_SPLIT ? V2A_BF16 : a->out_dtype, s);
     }
+    // (a 128x128 tile whose two wave groups alternate along K -- one multiplies a stage while the other reads and stages the next -- was built
+    // and measured in round 5: 20-25 % slower than shape 7, bound by the DMA issue of its loading waves; profiles/r05_pingpong_probe.txt, source
+    // kept as scripts/probes/gemm_pingpong.hip.txt)
     if (cfg == 0) {
       // (stand-alone, scripts/split_probe.py, profiles/r05_split_probe.txt)
       if (a->epilogue == V2A_EPI_GEGLU || a->N >= 2048) cfg = nt(128, 128) >= 200 ? 3 : 4;
