@@ -448,6 +448,8 @@ def summary_fields(res):
             # fast bf16 mode (outside north_star's tolerance: reported, never `value`), where the driver's parser keeps them
             roof["parity_max_abs_delta_mel_over_grid"] = max(hp["max_abs_delta_mel_over_grid"], hp["max_abs_delta_mel"])
             roof["parity_meets_1e-3"] = bool(hp["meets_1e-3"])
+            roof["parity_against"] = ("CPU restatement oracle/e2_cfm_oracle.py (in-tree blocks pinned by the reference's own code; x-transformers / torchdiffeq arithmetic "
+                                      "restated from the call sites, unpinned: DESIGN 0; A7 reading: no rotary in cross-attention)")
             roof["parity_fixture_mel_frames_per_s"] = hp["mel_frames_per_s"]
             if "clips8_max_abs_delta_mel" in hp:
                 roof["clips8_parity_max_abs_delta_mel"] = hp["clips8_max_abs_delta_mel"]

@@ -139,6 +139,13 @@ typedef struct v2a_gemm_args {
    * v2a_split_bf16 pass.  Likewise out_dtype = V2A_BF16_SPLIT (GEGLU epilogue only): out row m = [hi | lo] planes of the N/2
    * hidden values, ldo >= N, exact erf GELU. */
   int32_t out_bf16_split;
+  /* ABI 8, split operands / split shadow only.  a_lo_offset[s]: elements from the hi plane of a row of segment s to its lo plane; 0 = ka[s], the
+   * layout [hi k | lo k].  out_bf16_lo_offset: the same for the shadow row; 0 = N.  They let ONE buffer of rows [x_hi | s_hi | x_lo | s_lo] serve
+   * as a K = 2d segment (x and the U-Net skip concatenated, lo plane 2d further) AND, half by half, as a K = d segment or as the split shadow
+   * two different GEMM epilogues write (lo plane 2d further, not d): the fused cross-condition + skip projection of the bf16x3 mode.
+   * Multiples of 8 (a_lo_offset) / 4 (out_bf16_lo_offset); lda[s] >= a_lo_offset[s] + ka[s], ld_out_bf16 >= out_bf16_lo_offset + N. */
+  int64_t a_lo_offset[3];
+  int64_t out_bf16_lo_offset;
 } v2a_gemm_args;
 
 int v2a_gemm(const v2a_gemm_args* args, v2a_stream_t stream);

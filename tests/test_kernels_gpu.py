@@ -743,6 +743,41 @@ def test_gemm_split_native(L, hint, epi, M, N, ks):
         assert err < 4e-5 * max(float(ref.abs().max()), 1.0), err
 
 
+@pytest.mark.parametrize("hint", [0, 4, 5, 6])
+def test_gemm_split_plane_offsets(L, hint):
+    """v2a_gemm_args.a_lo_offset / out_bf16_lo_offset: ONE buffer of rows [x_hi | s_hi | x_lo | s_lo] read as a K = 2d split segment (lo plane
+    2d further: the default) and, half by half, as K = d segments whose lo plane lies 2d -- not d -- behind the hi plane; and a split
+    shadow written into one half of such a buffer.  Equal bit for bit to the same GEMMs on separately laid out operands."""
+    M, d, N = 1564 if hint == 5 else 300, 256, 1024
+    g = _g(50 + hint)
+    x, sk = torch.randn(M, d, generator=g), torch.randn(M, d, generator=g)
+    w = torch.randn(N, 2 * d, generator=g) / math.sqrt(2 * d)
+    xs, ss = _split_planes(x), _split_planes(sk)
+    wide = torch.cat([xs[:, :d], ss[:, :d], xs[:, d:], ss[:, d:]], 1).contiguous().to(DEV)      # [x_hi | s_hi | x_lo | s_lo]
+    wd = _split_planes(w).to(DEV)
+    kw = dict(M=M, N=N, compute=L.BF16, a_split=True, tile_hint=hint)
+    ref, got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    L.gemm([(xs.to(DEV), 2 * d, d), (ss.to(DEV), 2 * d, d)], wd, ref, **kw)                           # two standard segments
+    L.gemm([(wide, 4 * d, 2 * d)], wd, got, **kw)                                                       # the wide buffer as one K = 2d segment
+    assert torch.equal(got, ref)
+    got.zero_()
+    L.gemm([(wide, 4 * d, d, 2 * d), (wide[:, d:], 4 * d, d, 2 * d)], wd, got, **kw)                    # its halves as K = d segments, lo plane 2d further
+    assert torch.equal(got, ref)
+    # a split shadow written into the skip half of a wide buffer == the standard shadow, plane by plane
+    res = torch.randn(M, d, generator=g).to(DEV)
+    w2 = _split_planes(torch.randn(d, d, generator=g) / 16).to(DEV)
+    o1, o2 = torch.empty(M, d, device=DEV), torch.empty(M, d, device=DEV)
+    sh = torch.zeros(M, 2 * d, dtype=torch.bfloat16, device=DEV)
+    wide2 = torch.zeros(M, 4 * d, dtype=torch.bfloat16, device=DEV)
+    ekw = dict(M=M, N=d, compute=L.BF16, a_split=True, epilogue=L.EPI_RESID, resid=res, out_bf16_split=True, tile_hint=0 if hint == 5 else hint)
+    L.gemm([(xs.to(DEV), 2 * d, d)], w2, o1, out_bf16=sh, ld_out_bf16=2 * d, **ekw)
+    L.gemm([(xs.to(DEV), 2 * d, d)], w2, o2, out_bf16=wide2[:, d:], ld_out_bf16=4 * d, out_bf16_lo_offset=2 * d, **ekw)
+    assert torch.equal(o1, o2) and torch.equal(wide2[:, d:2 * d], sh[:, :d]) and torch.equal(wide2[:, 3 * d:], sh[:, d:])
+    assert float(wide2[:, :d].abs().max()) == 0 and float(wide2[:, 2 * d:3 * d].abs().max()) == 0
+    with pytest.raises(L.V2AError, match="a_lo_offset"):
+        L.gemm([(wide, 4 * d, d, 2 * d + 4)], wd[:, :2 * d].contiguous(), got, M=M, N=N, compute=L.BF16, a_split=True)
+
+
 def test_gemm_split_native_folded_norm_consumer(L):
     """... and as the CONSUMER of a folded RMSNorm: A = split(x * gamma), the accumulator row scaled by sqrt(d) / |x| before the bias."""
     M, K, N = 300, 512, 256

@@ -330,6 +330,30 @@ def test_bf16_fused_cross_condition_and_skip_match_two_gemms(small, golden, case
     assert float(d.mean()) < 0.013 and float(d.max()) < 0.065 and e[0] < 1.2 * e[1] + 0.002     # measured 0.0088 / 0.042; 0.0081 vs 0.0088
 
 
+@pytest.mark.parametrize("case", ["full", "ragged"])
+def test_bf16x3_fused_cross_condition_and_skip_match_two_gemms(small, golden, case):
+    """bf16x3 mode (round 5): the same fusion on split operands -- the x and skip halves of one [x_hi | s_hi | x_lo | s_lo] buffer, weights multiplied
+    out in fp64 and split into hi | lo planes -- against the two GEMMs: agreement to split-bf16 noise, and both inside 1e-3 of the fp32 golden."""
+    i, g = small["inp"], golden["sample_small"]
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling=True, remove_parallel_component=False, return_raw_output=True)
+    key = "y_full"
+    if case == "ragged":
+        kw.update(lens=torch.tensor([40, 29]), duration=torch.tensor([40, 29]))
+        key = "y_ragged"
+    outs = []
+    for fuse in (True, False):
+        m = make_model(small["cfg"], small["P"], "bf16x3")
+        m.engine().fuse_skip = fuse
+        assert m.engine()._fuse_skip() == fuse
+        o = m.sample(torch.zeros(2, 40, small["cfg"].num_channels), y0=i["y0"], text_embed=i["text"], context=i["ctx"],
+                     context_mask=i["ctx_mask"], frames_embed=i["roll"], **kw)
+        outs.append(o.float().cpu())
+    d = float((outs[0] - outs[1]).abs().max())
+    e = [float((o - torch.from_numpy(g[key])).abs().max()) for o in outs]
+    print(f"bf16x3 fused vs two-GEMM skip [{case}]: max {d:.2e}; max |delta| vs fp32 golden {e[0]:.2e} / {e[1]:.2e}")
+    assert d < 3e-4 and e[0] < 1e-3 and e[1] < 1e-3
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_plan_cache_and_buckets(small, mode):
     """Real traffic (predict.py:210-237: captions and durations vary per clip).  (a) Alternating between two (frames, context)

@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
         ("norm_ssq", C.c_void_p), ("ld_norm_ssq", C.c_int64),
         ("row_ssq", C.c_void_p), ("ld_row_ssq", C.c_int64), ("row_ssq_parts", C.c_int32), ("row_norm_dim", C.c_int32),
         ("out_bf16_split", C.c_int32),
+        ("a_lo_offset", C.c_int64 * 3), ("out_bf16_lo_offset", C.c_int64),
     ]
 
 
@@ -290,17 +291,21 @@ def gemm_args(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, r
          out_bf16=None, ld_out_bf16=None, rope_table=None, rope_cols=0, rope_pos_offset=0, relu=False,
          a_row_offset=None, a_ktile_offset=None, out_row_offset=None, tile_hint=0,
          norm_gamma=None, norm_step_stride=0, norm_batch_stride=0, norm_switch_row=0, norm_switch_offset=0, norm_ssq=None,
-         row_ssq=None, row_norm_dim=0, out_bf16_split=False, a_split=False, out_split=False):
+         row_ssq=None, row_norm_dim=0, out_bf16_split=False, a_split=False, out_split=False, out_bf16_lo_offset=0):
     """a_segs: list of (tensor_or_ptr_view, lda, k).  w: [N][K] tensor in the compute dtype.
-    a_split: the segments are V2A_BF16_SPLIT rows ([hi k | lo k], lda >= 2k) and w is [N][2K] = [W_hi | W_lo] (the bf16x3 mode's native
+    a_split: the segments are V2A_BF16_SPLIT rows ([hi k | lo k], lda >= 2k; a segment may be a 4-tuple whose last element is the offset of its
+    lo plane when that is not k: v2a_gemm_args.a_lo_offset) and w is [N][2K] = [W_hi | W_lo] (the bf16x3 mode's native
     GEMM: three MFMA products per fp32 product); out_split: GEGLU output as hi | lo planes; out_bf16_split: the shadow likewise.
     Folded RMSNorm (v2a_gemm_args): producer -- norm_gamma (+ strides / switch) scales the out_bf16 shadow, norm_ssq (rows, N/32)
     receives the sums of squares; consumer -- row_ssq (rows, parts) of its A rows and row_norm_dim = their width."""
     g = GemmArgs()
-    for i, (t, lda, k) in enumerate(a_segs):
+    for i, seg in enumerate(a_segs):
+        t, lda, k = seg[:3]
         g.a[i] = t.data_ptr()
         g.lda[i] = lda
         g.ka[i] = k
+        g.a_lo_offset[i] = seg[3] if len(seg) > 3 else 0
+    a_segs = [seg[:3] for seg in a_segs]
     g.nseg = len(a_segs)
     g.a_dtype = BF16_SPLIT if a_split else dt_code(a_segs[0][0].dtype)
     g.w = w.data_ptr()
@@ -336,6 +341,7 @@ def gemm_args(a_segs, w, out, *, M, N, compute, epilogue=EPI_STORE, bias=None, r
     g.row_ssq_parts = row_norm_dim // 32 if row_ssq is not None else 0
     g.row_norm_dim = row_norm_dim
     g.out_bf16_split = 1 if out_bf16_split else 0
+    g.out_bf16_lo_offset = out_bf16_lo_offset
     K = sum(k for _, _, k in a_segs)
     key = "gemm<%s,%s,%s,%s>" % ("bf16" if compute == BF16 else "f32", "a_f32" if g.a_dtype == F32 else ("a_split" if a_split else "a_bf16"),
                                  _EPI_NAMES[epilogue], "f32" if g.out_dtype == F32 else "bf16")

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
   int seg = 0;
   int seg_left = (nseg > 1 ? p.kend[0] : p.K) / BK;       // K tiles left in the current segment
   // S3: byte offset of the lo plane inside an A row (= the segment's K extent) and inside a W row (= K)
-  int64_t a_lo_bytes = S3 ? (int64_t)(nseg > 1 ? p.kend[0] : p.K) * 2 : 0;
+  int64_t a_lo_bytes = S3 ? p.alo[0] * 2 : 0;
   const int64_t w_lo_bytes = S3 ? (int64_t)p.K * 2 : 0;
   int kt_next = 0;                                        // index of the next K tile to issue (offset-table path only)
   auto issue = [&](int stage) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
       ++seg;
       a_run = reinterpret_cast<const char*>(seg == 1 ? p.a[1] : p.a[2]);
       seg_left = (seg == 1 ? (nseg > 2 ? p.kend[1] : p.K) - p.kend[0] : p.K - p.kend[1]) / BK;
-      if constexpr (S3) a_lo_bytes = (int64_t)seg_left * ROWB;
+      if constexpr (S3) a_lo_bytes = (seg == 1 ? p.alo[1] : p.alo[2]) * 2;
       set_offsets(seg == 1 ? p.lda[1] : p.lda[2]);
     }
     const char* ab = a_run;
@@ -596,7 +596,20 @@ static int gemm_prepare(const v2a_gemm_args* a, GemmParams& p) {
   p.ldo2 = a->ld_out_bf16;
   if (a->out_bf16) V2A_REQUIRE(a->out_dtype == V2A_F32 && a->epilogue != V2A_EPI_GEGLU, "v2a_gemm: out_bf16 shadows an fp32 output only");
   p.out2_split = a->out_bf16 && a->out_bf16_split ? 1 : 0;
-  if (p.out2_split) V2A_REQUIRE(a->ld_out_bf16 >= 2 * (int64_t)a->N, "v2a_gemm: a split shadow needs ld_out_bf16 >= 2 * N");
+  p.out2_lo = a->out_bf16_lo_offset > 0 ? a->out_bf16_lo_offset : a->N;
+  if (p.out2_split)
+    V2A_REQUIRE(p.out2_lo >= a->N && p.out2_lo % 4 == 0 && a->ld_out_bf16 >= p.out2_lo + (int64_t)a->N,
+                "v2a_gemm: a split shadow needs out_bf16_lo_offset (%lld) >= N, a multiple of 4, and ld_out_bf16 >= lo offset + N", (long long)p.out2_lo);
+  else
+    V2A_REQUIRE(a->out_bf16_lo_offset == 0, "v2a_gemm: out_bf16_lo_offset goes with out_bf16_split");
+  for (int sg = 0; sg < a->nseg; ++sg) {
+    p.alo[sg] = a->a_lo_offset[sg] > 0 ? a->a_lo_offset[sg] : a->ka[sg];
+    if (split_in)
+      V2A_REQUIRE(p.alo[sg] >= a->ka[sg] && p.alo[sg] % 8 == 0 && a->lda[sg] >= p.alo[sg] + (int64_t)a->ka[sg],
+                  "v2a_gemm: split segment %d: a_lo_offset (%lld) must be >= K, a multiple of 8, and lda >= lo offset + K", sg, (long long)p.alo[sg]);
+    else
+      V2A_REQUIRE(a->a_lo_offset[sg] == 0, "v2a_gemm: a_lo_offset goes with split operands");
+  }
   p.out_split = a->out_dtype == V2A_BF16_SPLIT ? 1 : 0;
   if (p.out_split) V2A_REQUIRE(a->epilogue == V2A_EPI_GEGLU && a->ldo >= a->N, "v2a_gemm: out_dtype V2A_BF16_SPLIT goes with the GEGLU epilogue and ldo >= N");
   p.resid = a->resid;

@@ -97,9 +97,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   // plane of its A segment (the segment's K extent further along the row), pass 1 the lo plane of W (s3_kl elements further along the row)
   const int kl = p.s3_kl;
   const int nkl = kl > 0 ? kl / 64 : 0x3fffffff;                 // plain operands: every K tile is in "pass 0"
-  const int sb0 = kl > 0 ? 2 * (nseg > 1 ? p.kend[0] : kl) : 0;  // bytes from a row's hi plane to its lo plane, by segment
-  const int dsb1 = kl > 0 && nseg > 1 ? 2 * ((nseg > 2 ? p.kend[1] : kl) - p.kend[0]) - sb0 : 0;
-  const int dsb2 = kl > 0 && nseg > 2 ? 2 * (kl - p.kend[1]) - (sb0 + dsb1) : 0;
+  const int sb0 = kl > 0 ? (int)(2 * p.alo[0]) : 0;              // bytes from a row's hi plane to its lo plane, by segment (GemmParams::alo)
+  const int dsb1 = kl > 0 && nseg > 1 ? (int)(2 * p.alo[1]) - sb0 : 0;
+  const int dsb2 = kl > 0 && nseg > 2 ? (int)(2 * p.alo[2]) - (sb0 + dsb1) : 0;
   const int64_t wlo = (int64_t)kl * 2;
   auto stage_a = [&](int s, int kt, int buf) {
     const bool p1 = kt >= nkl, p2 = kt >= 2 * nkl;         // p2 implies p1

@@ -57,6 +57,8 @@ struct GemmParams {
   // split (hi | lo plane) outputs of the bf16x3 mode: out2 = the shadow (lo plane N columns after hi), out = the GEGLU hidden
   // (lo plane N / 2 columns after hi)
   int32_t out2_split, out_split;
+  int64_t alo[3];           // split operands: elements from a row's hi plane to its lo plane, per segment (default: the segment's K extent)
+  int64_t out2_lo;          // split shadow: elements from the hi plane to the lo plane of a shadow row (default: N)
   // 8-phase kernel, split (hi | lo plane) operands: s3_kl = the LOGICAL K (sum of the segments' extents), K = 3 * s3_kl, and the K loop
   // walks the logical K three times: pass 0 = A_hi x W_hi, pass 1 = A_hi x W_lo, pass 2 = A_lo x W_hi -- every pass over all (up to
   // three) logical segments, whose rows are [hi k | lo k] (lda >= 2k), against weight rows [W_hi (s3_kl) | W_lo (s3_kl)].  0 = plain operands
@@ -588,7 +590,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
               bf16x4 lo;
 #pragma unroll
               for (int e = 0; e < 4; ++e) lo[e] = (bf16_t)(v[e] * gm[e] - (float)o[e]);
-              *reinterpret_cast<bf16x4*>(out2 + o_out2 + p.N + n) = lo;
+              *reinterpret_cast<bf16x4*>(out2 + o_out2 + p.out2_lo + n) = lo;
             }
             if (p.ssq) {
               const float ss = octet_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);

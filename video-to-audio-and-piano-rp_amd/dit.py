@@ -160,8 +160,8 @@ class PackedWeights:
             ly = {}
             if i >= c.depth // 2:
                 ly["skip"] = pk(sd[f"{P}.0.0.weight"], [c.dim, c.dim])
-                if cd == torch.bfloat16 and not split:
-                    # cross-condition and U-Net skip of the second half as ONE GEMM (bf16 mode; both Linears are bias-free):
+                if cd == torch.bfloat16:
+                    # cross-condition and U-Net skip of the second half as ONE GEMM (bf16 mode, and since round 5 bf16x3: both Linears are bias-free):
                     #   skip_proj(cat(x + W1 [x; t; f], s)) = Ws_x (I + W1_a) x + Ws_s s + (Ws_x W1_t) t + (Ws_x W1_f) f
                     # K = 3840 instead of 2816 + 2048, one launch instead of two on the audio stream's critical path.  Column
                     # order [x | s | t | f]: x and s are the two halves of one 2048-wide bf16 operand buffer (DiTEngine).
@@ -372,20 +372,22 @@ class DiTEngine:
         # bf16 shadows of the fp32 residual streams (written by the producing GEMM epilogues): the
         # operands of the cross-condition / skip GEMMs, so those run on the LDS-DMA bf16 kernel too
         p["shadow"] = {}
+        p["lo_off"] = {}            # bf16x3: split operand views whose lo plane is NOT k elements behind the hi plane (by data pointer)
         if cd == torch.bfloat16:
             mk = lambda t: torch.empty(*t.shape[:-1], w2 * t.shape[-1], dtype=cd, device=dev)
             for name in ("xA", "xB", "tA", "tB", "tL0", "fA", "fB", "fL0"):
                 p["shadow"][p[name].data_ptr()] = mk(p[name])
-            if self.split:
-                for sk in p["skips"]:
-                    p["shadow"][sk.data_ptr()] = mk(sk)
-            else:
-                # [x entering layer depth-1-j | skip j] as one 2048-wide operand buffer per skip: the fused cross-condition +
-                # skip GEMM reads both halves as ONE K segment; the halves are written by the FF2 epilogue of layer
-                # depth-2-j (x's shadow) and by the cross-condition epilogue of layer j (skip j's shadow)
-                p["wide"] = [torch.empty(Bt, N, 2 * D, dtype=cd, device=dev) for _ in p["skips"]]
-                for sk, wd in zip(p["skips"], p["wide"]):
-                    p["shadow"][sk.data_ptr()] = wd[..., D:]
+            # [x entering layer depth-1-j | skip j] as one 2048-wide operand buffer per skip: the fused cross-condition +
+            # skip GEMM reads both halves as ONE K segment; the halves are written by the FF2 epilogue of layer
+            # depth-2-j (x's shadow) and by the cross-condition epilogue of layer j (skip j's shadow).  bf16x3: rows are
+            # [x_hi | s_hi | x_lo | s_lo] -- the lo plane of either half lies 2 D further, not D (`lo_off`: v2a_gemm_args.a_lo_offset /
+            # out_bf16_lo_offset), so that the buffer is a K = 2 D split segment as a whole and a K = D one half by half
+            p["wide"] = [torch.empty(Bt, N, w2 * 2 * D, dtype=cd, device=dev) for _ in p["skips"]]
+            for sk, wd in zip(p["skips"], p["wide"]):
+                p["shadow"][sk.data_ptr()] = wd[..., D:2 * D]
+                if self.split:
+                    p["lo_off"][wd.data_ptr()] = 2 * D                       # the whole buffer, or its x half
+                    p["lo_off"][wd[..., D:2 * D].data_ptr()] = 2 * D         # its skip half
         p["q2"] = e(B * N, W0["a_attn2"].n_pad, dt=self.ad)
         inner = c.heads * c.dim_head
         p["ctx_kv"] = e(B * nc, 2 * c.depth * inner, dt=self.ad)
@@ -450,9 +452,11 @@ class DiTEngine:
             kw["ld_out_bf16"] = kw["out_bf16"].stride(-2)        # a shadow may be half of a wider operand buffer
         if not self.split:
             return L.gemm(segs, W, out, compute=self.cdc, **kw)
-        segs = [(buf, buf.stride(-2), k) for buf, _, k in segs]
+        lo = self.plan["lo_off"]
+        segs = [(buf, buf.stride(-2), k, lo.get(buf.data_ptr(), 0)) for buf, _, k in segs]
         if kw.get("out_bf16") is not None:
             kw["out_bf16_split"] = True
+            kw["out_bf16_lo_offset"] = lo.get(kw["out_bf16"].data_ptr(), 0)
         return L.gemm(segs, W, out, compute=L.BF16, a_split=True, **kw)
 
     def _norm_plain(self, x, hn, rows, d, g):
@@ -468,7 +472,7 @@ class DiTEngine:
             L.rmsnorm(x, hn, rows=rows, d=d, gamma=tab, step=p["step"], gamma_step_stride=ss, rows_per_batch=p["N"], split=self.split)
 
     def _fuse_skip(self):
-        return self.fuse_skip and not self.split and self.cd == torch.bfloat16 and "x_skip" in self.W.layers[-1]
+        return self.fuse_skip and self.cd == torch.bfloat16 and "x_skip" in self.W.layers[-1]
 
     def _fold(self):
         c = self.cfg
