@@ -67,25 +67,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   // ---- LDS-DMA source geometry: wave w fills 8-row groups w and w + 8 of every half tile
   const int srow = lane >> 3;
   const uint32_t schunk_b = (uint32_t)(((lane & 7) ^ srow) << 4);   // byte offset of the logical chunk this lane fetches
-  int arow[2][2];            // global A row per (half s, group i)
   uint32_t woff[2][2];       // byte offset into W per (half s, group i)
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 8 * (wave + 8 * i) + srow;                 // local row of the half tile
-      const int ar = m0 + r + ((r >= 64) ? 64 : 0) + 64 * s;
-      arow[s][i] = ar < p.M ? ar : p.M - 1;
       const int wrw = n0 + 64 * (r >> 5) + (r & 31) + 32 * s;
       woff[s][i] = (uint32_t)(((int64_t)(wrw < p.N ? wrw : p.N - 1) * p.ldw) * 2) + schunk_b;
     }
   const char* wbase = reinterpret_cast<const char*>(p.w);
   const int nk = p.K / 64;
 
-  // segment table as scalar base + deltas: inside the K loop a segment switch is two s_cselect per quantity, not a
-  // kernel-argument load (whose s_waitcnt lgkmcnt(0) would also wait for the phase's fragment reads before the DMA could
-  // issue).  Deltas rather than a select between the three values themselves: a select of two captured variables becomes
-  // a load through a selected address, which keeps the whole closure on the stack (176 B of scratch per lane, measured).
+  // segment table as scalar base + deltas: a segment switch is two s_cselect per quantity, not a kernel-argument load.  Deltas rather
+  // than a select between the three values themselves: a select of two captured variables becomes a load through a selected address,
+  // which keeps the whole closure on the stack (176 B of scratch per lane, measured).
   const int nseg = p.nseg;
   const int64_t a0 = (int64_t)p.a[0];
   const int64_t da1 = nseg > 1 ? (int64_t)p.a[1] - a0 : 0, da2 = nseg > 2 ? (int64_t)p.a[2] - (int64_t)p.a[1] : 0;
@@ -94,37 +90,68 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   const int kend0 = nseg > 1 ? p.kend[0] : 0x7fffffff, kend1 = nseg > 2 ? p.kend[1] : 0x7fffffff;
   const int dk2 = nseg > 2 ? p.kend[1] - p.kend[0] : 0;
   // split operands (GemmParams::s3_kl): K tile kt belongs to pass kt / nkl and is K tile kt % nkl of the logical K; pass 2 reads the lo
-  // plane of its A segment (the segment's K extent further along the row), pass 1 the lo plane of W (s3_kl elements further along the row)
+  // plane of its A segment (GemmParams::alo further along the row), pass 1 the lo plane of W (s3_kl elements further along the row)
   const int kl = p.s3_kl;
   const int nkl = kl > 0 ? kl / 64 : 0x3fffffff;                 // plain operands: every K tile is in "pass 0"
-  const int sb0 = kl > 0 ? (int)(2 * p.alo[0]) : 0;              // bytes from a row's hi plane to its lo plane, by segment (GemmParams::alo)
+  const int klog = kl > 0 ? kl : p.K;                            // the logical K
+  const int sb0 = kl > 0 ? (int)(2 * p.alo[0]) : 0;              // bytes from a row's hi plane to its lo plane, by segment
   const int dsb1 = kl > 0 && nseg > 1 ? (int)(2 * p.alo[1]) - sb0 : 0;
   const int dsb2 = kl > 0 && nseg > 2 ? (int)(2 * p.alo[2]) - (sb0 + dsb1) : 0;
   const int64_t wlo = (int64_t)kl * 2;
-  auto stage_a = [&](int s, int kt, int buf) {
+  // Operand streams (round 5).  Each of the three DMA streams -- A half 0, A half 1, W (both halves) -- is issued strictly in K-tile order, so
+  // each keeps a RUNNING wave-uniform base pointer stepped by 128 B per K tile and a count of K tiles left in its (pass, segment); per-lane
+  // row offsets (row x the segment's row stride) are VGPRs set up per (pass, segment).  Deriving pass, segment, base and row stride of EVERY K
+  // tile from kt cost ~45 scalar instructions and two 64-bit multiply-adds per staging call -- ~350 cycles of issue in the load part of a
+  // phase whose partner multiplies for 256: the load parts, not the MFMAs, paced the loop (profiles/r05_8phase_even_bands_ab.txt).
+  const char* aptr[2];
+  int aleft[2] = {0, 0};
+  uint32_t aoff[2][2];
+  auto a_setup = [&](int s, int kt) {
     const bool p1 = kt >= nkl, p2 = kt >= 2 * nkl;         // p2 implies p1
     const int k0 = (kt - (p1 ? nkl : 0) - (p2 ? nkl : 0)) * 64;
     const bool s1 = k0 >= kend0, s2 = k0 >= kend1;       // s2 implies s1
     const int kbeg = (s1 ? kend0 : 0) + (s2 ? dk2 : 0);
     const int lo = p2 ? sb0 + (s1 ? dsb1 : 0) + (s2 ? dsb2 : 0) : 0;
-    const char* ab = reinterpret_cast<const char*>(a0 + (s1 ? da1 : 0) + (s2 ? da2 : 0)) + (int64_t)(k0 - kbeg) * 2 + lo;
+    aptr[s] = reinterpret_cast<const char*>(a0 + (s1 ? da1 : 0) + (s2 ? da2 : 0)) + (int64_t)(k0 - kbeg) * 2 + lo;
     const uint32_t ldb = (uint32_t)(ldb0 + (s1 ? dl1 : 0) + (s2 ? dl2 : 0));
-    char* dst = smem_raw + buf * BUF + s * HALF;
+    const int kstop = min(klog, s2 ? 0x7fffffff : (s1 ? kend1 : kend0));   // end of this segment within the pass
+    aleft[s] = (kstop - k0) >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const uint32_t off = (uint32_t)arow[s][i] * ldb + schunk_b;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + off),
-                                       (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+      const int r = 8 * (wave + 8 * i) + srow;                 // local row of the half tile
+      const int ar = m0 + r + ((r >= 64) ? 64 : 0) + 64 * s;
+      aoff[s][i] = (uint32_t)(ar < p.M ? ar : p.M - 1) * ldb + schunk_b;
     }
   };
-  auto stage_b = [&](int s, int kt, int buf) {
-    const bool p1 = kt >= nkl, p2 = kt >= 2 * nkl;
-    const char* wb = wbase + (int64_t)(kt - (p1 ? nkl : 0) - (p2 ? nkl : 0)) * 128 + (p1 && !p2 ? wlo : 0);
-    char* dst = smem_raw + buf * BUF + (2 + s) * HALF;
+  auto stage_a = [&](int s, int kt, int buf) {
+    if (aleft[s] == 0) a_setup(s, kt);
+    char* dst = smem_raw + buf * BUF + s * HALF;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + woff[s][i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[s] + aoff[s][i]),
                                        (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+    aptr[s] += 128;
+    --aleft[s];
+  };
+  const char* wptr = wbase;
+  int wleft = 0;
+  auto stage_b = [&](int kt, int buf) {                    // both halves of W's K tile kt
+    if (wleft == 0) {
+      const bool p1 = kt >= nkl, p2 = kt >= 2 * nkl;
+      const int ktl = kt - (p1 ? nkl : 0) - (p2 ? nkl : 0);
+      wptr = wbase + (int64_t)ktl * 128 + (p1 && !p2 ? wlo : 0);
+      wleft = min(nkl, nk) - ktl;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      char* dst = smem_raw + buf * BUF + (2 + s) * HALF;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wptr + woff[s][i]),
+                                         (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+    wptr += 128;
+    --wleft;
   };
 
   // ---- fragment reads: row = sub-tile base + 16*i + lr, chunk = (4*kk + lq) ^ (row & 7) = ... ^ (lr & 7)
@@ -179,13 +206,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
   if (scaled && tid < 256) rowscale_load(p, m0 + tid, rsl);
   // ---- prologue: K tile 0 whole, plus the three halves of K tile 1 the steady state would have issued already
   stage_a(0, 0, 0);
-  stage_b(0, 0, 0);
-  stage_b(1, 0, 0);
+  stage_b(0, 0);
   stage_a(1, 0, 0);
   if (nk > 1) {
     stage_a(0, 1, 1);
-    stage_b(0, 1, 1);
-    stage_b(1, 1, 1);
+    stage_b(1, 1);
     if (scaled && tid < 256) rs_lds[tid] = rowscale_finish(p, rsl);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
@@ -225,10 +250,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     // P4: K tile t+1 (last piece: AH1 from P2) must have landed for every wave before anyone reads it (next P1 and later)
     if (t + 2 < nk) {
-      if (!(kSkip & 2)) {
-        stage_b(0, t + 2, B);
-        stage_b(1, t + 2, B);
-      }
+      if (!(kSkip & 2)) stage_b(t + 2, B);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
