@@ -388,7 +388,8 @@ def dwconv(x, out, wt, bias, *, B, N, d, ksize, lens=None, norm=None):
                                                        B, N, d, ksize, _p(lens), stream_ptr()))
         return
     n = _dwconv_norm(norm, d)
-    _launch("dwconv+norm", 2.0 * B * N * d * ksize, B * N * d * 10,
+    # x read + out written (fp32) + the normalised bf16 copy: one plane, or hi | lo planes in the split mode
+    _launch("dwconv+norm", 2.0 * B * N * d * ksize, B * N * d * (12 if n.split else 10),
             lambda: lib().v2a_dwconv_silu_residual_norm(x.data_ptr(), out.data_ptr(), wt.data_ptr(), bias.data_ptr(),
                                                         B, N, d, ksize, _p(lens), C.byref(n), stream_ptr()))
 

@@ -146,9 +146,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(GemmParams p) {
     for (int s = 0; s < 2; ++s) {
       char* dst = smem_raw + buf * BUF + (2 + s) * HALF;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wptr + woff[s][i]),
+      for (int i = 0; i < 2; ++i) {
+        // the 32-bit row offset is made opaque here: hoisted out of the K loop as a zero-extended 64-bit pair it cost a 64-bit vector add
+        // per DMA (and four more registers); as a 32-bit offset beside the scalar base the DMA takes it as is
+        uint32_t wo = woff[s][i];
+        asm volatile("" : "+v"(wo));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wptr + wo),
                                          (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+      }
     }
     wptr += 128;
     --wleft;
