@@ -348,8 +348,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
   auto tile = [&](auto stage_c, int kt) {
     constexpr int STAGE = decltype(stage_c)::value;
     // tile kt has landed for this wave once only the younger tile's DMAs remain outstanding
+#ifdef V2A_GEMM_PROBE   // K-loop attribution (scripts/probes/kloop_probe.py): bit 0 = no fragment reads / MFMAs, bit 1 = no DMA and no wait in the loop
+    if (!(p.dbg & 2))
+#endif
     ring_wait<NST - 2 < 0 ? 0 : NST - 2, LPW * (S3 ? 2 : 1)>(nk - 1 - kt);
     __builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading stage (kt-1) % NST
+#ifdef V2A_GEMM_PROBE
+    if (p.dbg & 1) {
+      if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
+      return;
+    }
+#endif
     const bf16_t* As = reinterpret_cast<const bf16_t*>(smem_raw + STAGE * STAGE_BYTES);
     const bf16_t* Ws = As + BM * BK;
     // all 32-wide K steps of the tile are requested before the first MFMA: the later ones' LDS latency runs under the
@@ -386,6 +395,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
           bfl[kk][j] = *reinterpret_cast<const bf16x8*>(Wl + row * BK + (((kk * 4 + lq) ^ swz(row)) << 3));
         }
       }
+#ifdef V2A_GEMM_PROBE
+      if (!(p.dbg & 2))
+#endif
       if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
@@ -407,6 +419,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_dma_kernel(const Gem
     } else {
     // the next tile's DMA is issued behind the first half's fragment reads: their LDS latency runs under the DMA issue
     // (~4 x LPW scalar instructions and LPW address translations) instead of after it
+#ifdef V2A_GEMM_PROBE
+    if (!(p.dbg & 2))
+#endif
     if (kt + NST - 1 < nk) issue((STAGE + NST - 1) % NST);
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
