@@ -236,8 +236,11 @@ TUNED_TILES = {
     # stages -- narrow GEMMs and feed-forward in on 128x256 (26 / 208 workgroups), QKV on 128x128: its chain has the slack (124 us per layer
     # stand-alone against the audio chain's 345), the CU-time it frees goes to the audio chain: +2.7 % (profiles/r05_bf16x3_tile_sweeps.txt,
     # sweeps 4 - 6).  The same on the text stream loses 0.6 - 3 %: its chain is as long as the audio chain's.
+    # ... and, once the 8-phase kernel's K loop had lost its address bookkeeping, the frames stream's two WIDE GEMMs on it: QKV
+    # (N = 1552: 49 workgroups instead of 91) and feed-forward in (N = 4096: 112 instead of 208), the cheapest tile per flop in chip-time: +0.9 %
+    # (sweep 7 of the same file).  Its narrow GEMMs stay on the ring: 14 tiles of 256x256 take 125 us each and the chain's slack is gone.
     ("bf16x3", 0, SHIPPED_WIDTHS): {("a", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt"), ("t", "qkv"): (5, "profiles/r04_bf16x3_qkv_8phase_ab.txt"),
-                                    ("f", "qkv"): (7, _R5), ("f", "ff1"): (6, _R5), ("f", "cross"): (6, _R5), ("f", "out"): (6, _R5), ("f", "ff2"): (6, _R5)},
+                                    ("f", "qkv"): (5, _R5), ("f", "ff1"): (5, _R5), ("f", "cross"): (6, _R5), ("f", "out"): (6, _R5), ("f", "ff2"): (6, _R5)},
     # bf16x3, launches that fill the chip several times over (8 clips per GPU): no entry.  The QKV projections on 128x256 tiles with 32-wide K
     # stages are 4-12 % faster stand-alone than on the 8-phase kernel (228 / 280 / 80 against 240 / 290 / 91 us: 637 tiles of 256x256 are 2.49
     # rounds, the 13th tile column holds 16 gate columns) and 1.2 % SLOWER in the sampler (3566 against 3608 mel-frames/s,
