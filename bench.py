@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--cross-on-main", action="store_true", help="A/B: all three cross-condition GEMMs on the main stream")
     ap.add_argument("--no-fuse-skip", action="store_true", help="A/B: cross-condition and skip projection as two GEMMs")
     ap.add_argument("--no-fuse-xattn", action="store_true", help="A/B: q-projection and cross-attention of the audio stream as two launches")
+    ap.add_argument("--fold-gemm-all", action="store_true", help="A/B: RMSNorms folded into GEMM epilogues at every batch size (default: up to two clips)")
     ap.add_argument("--no-fold-norm", action="store_true", help="A/B: separate RMSNorm launches instead of folding them into the neighbouring kernels")
     ap.add_argument("--big-tiles", default="", help="A/B: the same table for launches of more than two clips, e.g. a.qkv=0,t.ff2=6")
     ap.add_argument("--side-tiles", default="", help="A/B: per-(stream, op) tile configurations of the side-stream GEMMs, e.g. t.qkv=1,f.ff2=2 (ops: cross qkv out ff1 ff2; -1 = library choice)")
@@ -186,6 +187,8 @@ def main():
             table[(st_, op_)] = int(val)
     if args.no_fold_norm:
         model.engine().fold_norm = False
+    if args.fold_gemm_all:
+        model.engine().fold_gemm_all = True
     if args.no_fuse_skip:
         model.engine().fuse_skip = False
     if args.no_fuse_xattn:

@@ -308,6 +308,7 @@ class DiTEngine:
         # bf16 mode: the RMSNorms of the layer stack are folded into the kernel before them (gamma on the bf16 operand it writes,
         # sums of squares per 32 columns) and the GEMM after them (1 / rms per row in the epilogue): see _fold / _fold_gemm
         self.fold_norm = True
+        self.fold_gemm_all = False      # A/B: norms folded into GEMM epilogues at every batch size (default: up to two clips, see _fold_gemm)
         # bf16 and bf16x3 modes, up to three clips (bf16 stand-alone: 19.5 vs 23.2 us at three, 26.7 vs 25.7 at four): the audio stream's cross-attention as ONE launch (v2a_qproj_xattn: q-projection, RoPE, attention over
         # the <= 64 context keys and the head gate without the [q | gate] buffer in between); equal bit for bit to the two launches
         self.fuse_xattn = True
@@ -434,7 +435,7 @@ class DiTEngine:
         the tuning knobs on this object and the per-call state prepare() leaves in the plan."""
         p = self.plan
         return (p["ragged"], p["has_cond"], p["per_sample_t"], self.multi_stream, self.side_tile, tuple(sorted(self.side_tiles.items())),
-                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), tuple(sorted(self.split_big_tiles.items())), self.main_tile, self.fold_norm, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
+                tuple(sorted(self.big_tiles.items())), tuple(sorted(self.split_tiles.items())), tuple(sorted(self.split_big_tiles.items())), self.main_tile, self.fold_norm, self.fold_gemm_all, self.fuse_skip, self.fuse_xattn, self.cross_on_main,
                 self.interleave_capture, self.rope_cross, self.zero_masked_queries)
 
     # --------------------------------------------------------------------------- primitives
@@ -498,8 +499,9 @@ class DiTEngine:
     def _fold_gemm(self):
         """... into a GEMM epilogue only up to two clips: the extra bf16 row pieces cost an out-projection launch 2 us of 24 at
         one clip (a norm launch: 7.7 us) but 20-26 us of 58 at 8 clips per GPU, more than the 16.5 us norm launch they replace
-        (the conv fold wins at every size: 46 us against 49 + 16.5)."""
-        return self._fold() and self._regime() < 2
+        (the conv fold wins at every size: 46 us against 49 + 16.5).  Re-measured in the bf16x3 mode in round 5 (`bench.py --fold-gemm-all`, 8 clips,
+        alternating): 3960 / 3933, 3950 / 3924, 3949 / 3930 mel-frames/s -- the rule stands (-0.6 %)."""
+        return self._fold() and (self._regime() < 2 or self.fold_gemm_all)
 
     def _nprod_ada(self, layer, slot, switch_row=0):
         """Producer side of a folded AdaptiveRMSNorm (audio stream): kwargs for the RESID / GATE_RESID GEMM or the conv that
